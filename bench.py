@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- audio-sec / wall-sec (xRT) of the MI355X Whisper hot path.
+
+One "step" = one pass of the hot path (log-mel -> encoder -> cross-K/V -> batched greedy decode ->
+token ids on the host) over one batch of synthetic 30-second clips per GPU, PCM already resident in
+HBM.  Workload at N=1: BASELINE.json configs[2] -- distil-large-v3, fp16 storage / fp32 accumulate,
+batch 32.  N>1: every rank runs its own batch of distinct clips (weak scaling, no data-path
+collective; chunks are independent).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel = the encoder MFMA GEMM: achieved TFLOP/s from HIP events recorded
+                around every GEMM launch of the last timed step, on the stream the kernels run on
+  cpu_baseline  the CPU oracle (oracle/, a C restatement of the reference's candle CPU path) timed on
+                a bounded sample of the same workload on the box's host cores (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="distil-large-v3")
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--max-new-tokens", type=int, default=0,
+                    help="0 = reference behaviour (random weights run to the 447-token cap)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-new-tokens", type=int, default=8)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from norma_amd import assets_io, config, hip, synth, vocab
+    import common
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if hip.device_count() < 1:
+        raise RuntimeError("bench.py needs an MI355X; norma_amd has no CPU fallback")
+
+    cfg = config.preset(args.model)
+    tk = common.tokens_for(args.model)
+    B = args.batch
+    t_build = time.time()
+    hm = hip.HipWhisper(cfg, device=local_rank, max_batch=B)
+    hm.set_mel_filters(assets_io.mel_filters(cfg.num_mel_bins))
+    hm.set_tokens(tk, tk.en, tk.transcribe)
+    want_cpu = (not args.no_cpu_baseline) and world == 1 and rank == 0
+    om = None
+    if want_cpu:
+        from oracle import oracle as O
+        om = O.OracleModel(cfg, tk, tk.en, tk.transcribe)
+    for name, arr in synth.synth_weights(cfg, seed=0):  # seed-0 N(0, 0.02^2), fp16-representable
+        hm.load_tensor(name, arr.astype(np.float16))
+        if om is not None:
+            om.set_tensor(name, arr)
+    t_build = time.time() - t_build
+
+    # synthetic 16 kHz PCM, distinct clips per rank, resident in HBM before the timed region
+    clips = np.stack([synth.synth_pcm(rank * B + b) for b in range(B)])
+    pcm_dev = torch.from_numpy(clips).to(dev)
+    n_samples = [synth.N_SAMPLES] * B
+    torch.cuda.synchronize()
+
+    def step(max_new):
+        return hm.transcribe_batch_device(pcm_dev.data_ptr(), n_samples, synth.N_SAMPLES, max_new)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        hm.synchronize()
+
+    hm.set_profile_gemm(True)  # two hipEventRecord per GEMM launch (~400 per step, < 0.5 % of a step)
+    for _ in range(args.warmup):
+        res = step(args.max_new_tokens)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step(args.max_new_tokens)
+    barrier()
+    dt = time.perf_counter() - t0
+    tm = hm.timings()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    audio_s = world * B * 30.0 * args.steps
+    value = audio_s / dt
+
+    # second decode-length protocol: 128 new tokens per clip, untimed by the contract
+    extra = {}
+    if args.max_new_tokens == 0:
+        barrier()
+        t1 = time.perf_counter()
+        r128 = step(128)
+        barrier()
+        extra["xrt_128_new_tokens_per_gpu"] = B * 30.0 / (time.perf_counter() - t1)
+        extra["tokens_128"] = int(np.mean([len(r["tokens"]) for r in r128]))
+        tm128 = hm.timings()
+        extra["decode_ms_128"] = tm128["decode_ms"]
+
+    if rank == 0:
+        gemm_tflops = tm["gemm_flops"] / (tm["gemm_ms"] * 1e-3) / 1e12 if tm["gemm_ms"] > 0 else 0.0
+        peak = 2500.0  # dense fp16 MFMA peak of MI355X (MI355X_MICROARCH.md), TFLOP/s
+        out = {
+            "metric": "audio-sec/wall-sec (xRT) distil-large-v3 fp16 b32",
+            "value": value, "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"{args.model} fp16 batch={B} x 30 s clips per GPU, greedy decode "
+                                   f"{'to the 447-token cap (seed-0 random weights never emit eot)' if args.max_new_tokens == 0 else str(args.max_new_tokens) + ' new tokens'}",
+                       "batch_per_gpu": B, "clip_seconds": 30, "decode_tokens": int(np.mean([len(r['tokens']) for r in res])),
+                       "parallelism": f"chunk-dp{world}"},
+            "phases_ms": {k: tm[k] for k in ("mel_ms", "encoder_ms", "cross_kv_ms", "decode_ms")},
+            "decode_steps": tm["decode_steps"],
+            "roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel", "achieved": gemm_tflops, "peak": peak,
+                         "unit": "TFLOP/s", "frac": gemm_tflops / peak, "traffic": None,
+                         "launches": tm["gemm_launches"], "avg_launch_ms": tm["gemm_ms"] / max(tm["gemm_launches"], 1),
+                         "flops_per_step": tm["gemm_flops"]},
+            "extra": extra, "model_build_s": t_build,
+        }
+        if om is not None:
+            from oracle import oracle as O
+            clip = clips[0]
+            filt = assets_io.mel_filters(cfg.num_mel_bins)
+            c0 = time.perf_counter()
+            mel = O.pcm_to_mel(clip, filt)
+            xa = om.encoder_forward(mel)
+            r = om.decode(xa, use_kv_cache=False, max_new_tokens=args.cpu_new_tokens)  # reference structure: no self-attn KV cache
+            cdt = time.perf_counter() - c0
+            out["cpu_baseline"] = {
+                "value": 30.0 / cdt, "unit": "audio-sec/wall-sec", "cores": O.num_threads(), "kind": "port",
+                "sample": f"1 clip (30 s) of the same workload: log-mel + encoder + greedy decode capped at "
+                          f"{args.cpu_new_tokens} new tokens, f32, batch 1, no self-attention KV cache "
+                          f"({cdt:.1f} s of CPU work); C restatement of the reference's candle CPU path",
+                "seconds": cdt, "tokens": len(r["tokens"])}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    hm.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+/*
+ * norma_hip.h -- C ABI of libnorma_hip.so: the MI355X (gfx950) Whisper hot path for norma.
+ *
+ * This is the drop-in boundary a `norma-hip-sys` FFI crate binds.  Plain
+ * pointers and sizes only; no C++ or torch types.  Every function returns an int status
+ * (NH_OK == 0) and never throws or aborts; nh_last_error() gives the message for the last
+ * failure on that context.  A context is owned by one host thread (the reference's `Model` is
+ * `Send`, not `Sync`: src/models/mod.rs:24, src/lib.rs:377,462-464); use one context per GPU.
+ *
+ * All citations are relative to the reference repository MikeIvanichev/norma @ 2024_10_08.
+ *
+ * What each entry point replaces:
+ *   nh_create / nh_destroy        SelectedDevice -> device (src/models/mod.rs:47-55) and
+ *                                 Whisper::load (src/models/whisper/monolingual.rs:371-373)
+ *   nh_load_tensor                VarBuilder::from_mmaped_safetensors tensor reads by HF name
+ *                                 (monolingual.rs:237-239)
+ *   nh_set_mel_filters            the include_bytes! filterbank (monolingual.rs:351-362)
+ *   nh_set_tokens                 special-token ids + the four vocab masks (monolingual.rs:376-430)
+ *   nh_logmel                     audio::pcm_to_mel + Tensor::from_vec + narrow
+ *                                 (src/models/whisper/model.rs:74-88)
+ *   nh_encode                     Type::encoder_forward (model.rs:168, :455-464)
+ *   nh_decode_greedy              Model::decode at t = 0 (model.rs:279-389) including the logit
+ *                                 rules (model.rs:212-277), batched, on device
+ *   nh_encoder_output, nh_decoder_forward, nh_final_linear, nh_decode_probs
+ *                                 fine-grained views of the same state for layer-level parity:
+ *                                 Type::decoder_forward / decoder_final_linear (model.rs:466-483)
+ *   nh_reset                      Type::reset_kv_cache (model.rs:485-490)
+ */
+#ifndef NORMA_HIP_H
+#define NORMA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NH_OK 0
+#define NH_ERR_INVALID 1   /* bad argument / unknown tensor name / wrong shape */
+#define NH_ERR_HIP 2       /* a HIP runtime call failed (message has the hipError string) */
+#define NH_ERR_STATE 3     /* call sequence error (e.g. decode before encode) */
+#define NH_ERR_NOMEM 4
+
+#define NH_DTYPE_F32 0
+#define NH_DTYPE_F16 1
+
+#define NH_N_SAMPLES 480000 /* candle m::N_SAMPLES (model.rs:69)  */
+#define NH_N_FRAMES 3000    /* candle m::N_FRAMES  (model.rs:88)  */
+
+typedef struct nh_ctx nh_ctx; /* opaque; owns all device memory and one HIP stream */
+
+/* candle `Config` fields read from HF config.json (monolingual.rs:347). */
+typedef struct nh_config {
+    int32_t num_mel_bins;
+    int32_t max_source_positions; /* 1500 */
+    int32_t d_model;
+    int32_t encoder_attention_heads;
+    int32_t encoder_layers;
+    int32_t vocab_size;
+    int32_t max_target_positions; /* 448 */
+    int32_t decoder_attention_heads;
+    int32_t decoder_layers;
+} nh_config;
+
+/* norma `Model` token fields (model.rs:37-41) + ids used for first_token_supress. */
+typedef struct nh_tokens {
+    int32_t sot, eot;
+    int32_t lang;  /* language token pushed after sot (model.rs:286-288); < 0: none */
+    int32_t task;  /* transcribe / translate */
+    int32_t no_speech, no_timestamps;
+    int32_t zero_sec, one_sec; /* <|0.00|>, <|1.00|> */
+} nh_tokens;
+
+/* Result of one greedy decode (model.rs:494-499 DecodingResult, compression_ratio is always NaN). */
+typedef struct nh_decode_result {
+    int32_t n_tokens;       /* tokens written for this sequence, prompt and eot included */
+    int32_t no_speech_exit; /* 1: early return of model.rs:308-315 */
+    double avg_logprob;
+    double no_speech_prob;
+} nh_decode_result;
+
+/* ---- lifetime -------------------------------------------------------------------------------- */
+/* device_ordinal: SelectedDevice::Rocm(ord).  max_batch: chunks processed per call (>= 1). */
+int nh_create(int device_ordinal, const nh_config *cfg, int max_batch, nh_ctx **out);
+void nh_destroy(nh_ctx *ctx);
+const char *nh_last_error(const nh_ctx *ctx); /* ctx may be NULL: error of a failed nh_create */
+/* 1 when built for and running on a gfx950 device visible to HIP, else 0 (no side effects). */
+int nh_device_count(void);
+
+/* ---- model state ----------------------------------------------------------------------------- */
+/* name: HF tensor name, e.g. "model.encoder.layers.3.self_attn.q_proj.weight".  data: host
+ * pointer, row-major, dtype NH_DTYPE_*.  Tensors candle does not read
+ * ("model.encoder.embed_positions.weight", "proj_out.weight") are accepted and ignored. */
+int nh_load_tensor(nh_ctx *ctx, const char *name, int dtype, const int64_t *shape, int ndim,
+                   const void *data);
+/* filters: f32 [num_mel_bins][201] */
+int nh_set_mel_filters(nh_ctx *ctx, const float *filters, int n_mel);
+int nh_set_tokens(nh_ctx *ctx, const nh_tokens *tk, const int32_t *suppress_tokens, int n_suppress);
+/* Number of tensors still missing before the model can run (0 = complete). */
+int nh_missing_tensors(const nh_ctx *ctx);
+
+/* ---- the hot path ---------------------------------------------------------------------------- */
+/* pcm: host f32 mono 16 kHz, `batch` clips back to back with stride `stride` samples, clip b has
+ * n_samples[b] <= 480000 valid samples (the rest is treated as absent, exactly as pcm_to_mel pads
+ * with zeros).  Computes the log-mel of every clip on device. */
+int nh_logmel(nh_ctx *ctx, const float *pcm, const int32_t *n_samples, int64_t stride, int batch);
+/* Same, but pcm is a DEVICE pointer (already resident in HBM; no copy). */
+int nh_logmel_device(nh_ctx *ctx, const float *pcm_dev, const int32_t *n_samples, int64_t stride, int batch);
+/* Encoder forward over the mel of the last nh_logmel call (flush = true semantics: the cross
+ * K/V of every decoder layer is recomputed). */
+int nh_encode(nh_ctx *ctx);
+/* Greedy decode of all `batch` sequences.  out_tokens: host i32 [batch][max_target_positions],
+ * results: [batch].  max_new_tokens <= 0: reference behaviour (cap at max_target_positions - 1). */
+int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *results, int max_new_tokens);
+/* Device-resident log-mel -> encoder -> decode without intermediate host syncs (bench path). */
+int nh_transcribe_batch(nh_ctx *ctx, const float *pcm_dev, const int32_t *n_samples, int64_t stride,
+                        int batch, int32_t *out_tokens, nh_decode_result *results, int max_new_tokens);
+int nh_reset(nh_ctx *ctx);
+int nh_synchronize(nh_ctx *ctx);
+
+/* ---- fine-grained views for layer-level parity tests ------------------------------------------- */
+/* mel of clip b in candle layout: f32 [num_mel_bins][3000] */
+int nh_get_mel(nh_ctx *ctx, int b, float *out);
+/* Upload a mel directly (f32 [batch][num_mel_bins][3000]) instead of nh_logmel. */
+int nh_set_mel(nh_ctx *ctx, const float *mel, int batch);
+/* encoder output of clip b: f32 [1500][d_model] */
+int nh_encoder_output(nh_ctx *ctx, int b, float *out);
+/* TextDecoder::forward for every clip over a teacher-forced prefix: tokens i32 [batch][T] ->
+ * hidden f32 [batch][T][d_model] (after the final LayerNorm). */
+int nh_decoder_forward(nh_ctx *ctx, const int32_t *tokens, int T, float *hidden_out);
+/* TextDecoder::final_linear on host-provided rows: x f32 [rows][d_model] -> logits f32 [rows][V] */
+int nh_final_linear(nh_ctx *ctx, const float *x, int rows, float *logits_out);
+/* The logit rules on device: probs f32 [V] (already soft-maxed), tokens so far, last timestamp
+ * (< 0: first generated token).  Returns the masked probabilities (model.rs:333-338). */
+int nh_apply_rules(nh_ctx *ctx, const float *probs, const int32_t *tokens, int n_tokens,
+                   int last_timestamp, float *masked_out, int32_t *argmax_out);
+
+/* ---- instrumentation --------------------------------------------------------------------------- */
+/* Milliseconds (HIP events on the context's stream) spent in the phases of the last
+ * nh_transcribe_batch / nh_logmel+nh_encode+nh_decode_greedy sequence. */
+typedef struct nh_timings {
+    float mel_ms, encoder_ms, cross_kv_ms, decode_ms;
+    int32_t decode_steps;
+    float gemm_ms;      /* summed duration of the dominant encoder GEMM kernel launches */
+    int32_t gemm_launches;
+    double gemm_flops;  /* algorithmic FLOPs of those launches */
+} nh_timings;
+int nh_get_timings(nh_ctx *ctx, nh_timings *out);
+/* 1: bracket every encoder GEMM launch with HIP events (adds sync points; bench roofline only). */
+int nh_set_profile_gemm(nh_ctx *ctx, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NORMA_HIP_H */

@@ -1,0 +1,177 @@
+// k_attn_enc.hip -- encoder self-attention, flash style (gfx950 MFMA + LDS tiles).
+//
+// Replaces candle's MultiHeadAttention::qkv_attention for the AudioEncoder blocks (two batched
+// matmuls + softmax_last_dim materialising [B,H,1500,1500]; reached from Type::encoder_forward,
+// src/models/whisper/model.rs:455-464).  Scores never leave the chip: per 64-key tile
+// S^T = K Q^T (v_mfma_f32_32x32x16_f16), online softmax in registers (fp32, one query per lane,
+// max/sum finished with one cross-half shuffle), O^T += V^T P^T.
+//
+// Layout tricks (CDNA4 fragment maps, cdna_hip_programming.md 3):
+//  * "swapped" QK^T puts a query on the lane and the tile's keys in the 16 accumulator registers,
+//    so softmax is lane-local and the P registers are directly the B operand of the PV MFMA.
+//  * the accumulator's k order is row = 16s + 8(j>>2) + 4h + (j&3); storing K rows in LDS with
+//    bits 2 and 3 of the row index swapped makes that order "8 consecutive keys per (s,h)", so the
+//    V^T fragment is one aligned 16-byte LDS read.  V^T ([b][h][64][1536]) is written directly by
+//    the QKV GEMM epilogue (k_gemm.hip), never transposed here.
+//  * K and V^T tiles are [64 rows][128 B] images with chunk' = chunk ^ ((row >> 1) & 7):
+//    conflict-free ds_read_b128 for both fragment shapes.
+// The q/k pre-scaling by dh^-1/4 each is folded into one exact *1/8 inside the
+// exponent.  1500 keys are not a multiple of 64: the last tile masks keys >= S; V^T pad is zero.
+#include "nh_kernels.h"
+
+#define KT 64              // keys per tile
+#define QW 32              // queries per wave
+#define QB 128             // queries per workgroup
+#define TILE_B 8192        // bytes per K or V^T tile
+
+__device__ __forceinline__ int swap23(int x) { return (x & ~12) | ((x & 4) << 1) | ((x & 8) >> 1); }
+
+__global__ __launch_bounds__(256, 2) void enc_attn_kernel(const half_t *__restrict__ q, const half_t *__restrict__ k,
+                                                         long ld, const half_t *__restrict__ vt,
+                                                         half_t *__restrict__ out, long ldo, int S, int H) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_B];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * QB + w * QW;
+    const int nT = (S + KT - 1) / KT;
+
+    // Q fragments (B operand of S^T = K Q^T): lane (query r, half hh) holds Q[query][16 ks + 8 hh + j]
+    half8 qf[4];
+    {
+        int qrow = q0 + r; if (qrow >= S) qrow = S - 1;
+        const half_t *qp = q + ((long)b * S + qrow) * ld + h * NH_DH + 8 * hh;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) qf[ks] = *reinterpret_cast<const half8 *>(qp + 16 * ks);
+    }
+    // staging: slot s = tid + 256 i (i = 0,1): LDS row = s >> 3, chunk' = s & 7
+    const half_t *kg[2]; const half_t *vg[2];
+    int krow_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        int row = (tid >> 3) + 32 * i;
+        int c = (tid & 7) ^ ((row >> 1) & 7);
+        krow_off[i] = swap23(row);  // LDS row `row` holds key key0 + swap23(row)
+        kg[i] = k + (long)b * S * ld + h * NH_DH + c * 8;
+        vg[i] = vt + ((long)(b * H + h) * NH_DH + row) * NH_SP + c * 8;
+    }
+    u32x4 rk[2], rv[2];
+    auto load_tile = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            int key = t * KT + krow_off[i]; if (key >= S) key = S - 1;
+            rk[i] = *reinterpret_cast<const u32x4 *>(kg[i] + (long)key * ld);
+            rv[i] = *reinterpret_cast<const u32x4 *>(vg[i] + t * KT);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        u32x4 *lk = reinterpret_cast<u32x4 *>(smem + buf * 2 * TILE_B);
+        u32x4 *lv = reinterpret_cast<u32x4 *>(smem + buf * 2 * TILE_B + TILE_B);
+#pragma unroll
+        for (int i = 0; i < 2; i++) { lk[tid + 256 * i] = rk[i]; lv[tid + 256 * i] = rv[i]; }
+    };
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    // fragment byte offsets inside a tile (before adding the per-step chunk xor)
+    const int g = (r >> 1) & 7;                       // same for rows r and r + 32
+    const int offK0 = r * 128 + ((hh ^ g) << 4);      // K block 0 (rows 0..31); block 1 at + 4096
+    const int offV0 = r * 128 + ((hh ^ g) << 4);      // V^T dh block 0; block 1 at + 4096
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c_exp = 0.125f * 1.4426950408889634f;  // dh^-1/2 * log2(e)
+
+    int cur = 0;
+    for (int t = 0; t < nT; t++) {
+        const bool more = (t + 1 < nT);
+        if (more) load_tile(t + 1);
+        const char *tk = smem + cur * 2 * TILE_B, *tv = tk + TILE_B;
+        f32x16 s0, s1;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            // chunk 2 ks + hh: (2ks + hh) ^ g == (hh ^ g) ^ (2 ks)  -> byte offset ^ (ks << 5)
+            half8 k0 = *reinterpret_cast<const half8 *>(tk + (offK0 ^ (ks << 5)));
+            half8 k1 = *reinterpret_cast<const half8 *>(tk + 4096 + (offK0 ^ (ks << 5)));
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[ks], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[ks], s1, 0, 0, 0);
+        }
+        if (t * KT + KT > S) {  // last, partial tile: mask keys >= S
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                int rho = (i & 3) + 8 * (i >> 2) + 4 * hh;
+                int key0 = t * KT + swap23(rho), key1 = t * KT + 32 + swap23(rho);
+                if (key0 >= S) s0[i] = -INFINITY;
+                if (key1 >= S) s1[i] = -INFINITY;
+            }
+        }
+        float mx = s0[0];
+#pragma unroll
+        for (int i = 1; i < 16; i++) mx = fmaxf(mx, s0[i]);
+#pragma unroll
+        for (int i = 0; i < 16; i++) mx = fmaxf(mx, s1[i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
+        const float mb = m_new * c_exp;
+        float ps = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            s0[i] = __builtin_amdgcn_exp2f(s0[i] * c_exp - mb);
+            s1[i] = __builtin_amdgcn_exp2f(s1[i] * c_exp - mb);
+            ps += s0[i] + s1[i];
+        }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+        // P^T fragments (B operand): k-step (blk, s2) takes accumulator registers 8 s2 .. 8 s2 + 7
+        half8 p00, p01, p10, p11;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            p00[j] = (half_t)s0[j]; p01[j] = (half_t)s0[8 + j];
+            p10[j] = (half_t)s1[j]; p11[j] = (half_t)s1[8 + j];
+        }
+        // O^T[dh][q] += V^T[dh][keys] P^T[keys][q]; V^T chunk = 4 blk + 2 s2 + hh -> xor ((4blk+2s2) << 4)
+        {
+            half8 v;
+            v = *reinterpret_cast<const half8 *>(tv + (offV0 ^ (0 << 4)));          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, p00, o0, 0, 0, 0);
+            v = *reinterpret_cast<const half8 *>(tv + 4096 + (offV0 ^ (0 << 4)));   o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, p00, o1, 0, 0, 0);
+            v = *reinterpret_cast<const half8 *>(tv + (offV0 ^ (2 << 4)));          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, p01, o0, 0, 0, 0);
+            v = *reinterpret_cast<const half8 *>(tv + 4096 + (offV0 ^ (2 << 4)));   o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, p01, o1, 0, 0, 0);
+            v = *reinterpret_cast<const half8 *>(tv + (offV0 ^ (4 << 4)));          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, p10, o0, 0, 0, 0);
+            v = *reinterpret_cast<const half8 *>(tv + 4096 + (offV0 ^ (4 << 4)));   o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, p10, o1, 0, 0, 0);
+            v = *reinterpret_cast<const half8 *>(tv + (offV0 ^ (6 << 4)));          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, p11, o0, 0, 0, 0);
+            v = *reinterpret_cast<const half8 *>(tv + 4096 + (offV0 ^ (6 << 4)));   o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, p11, o1, 0, 0, 0);
+        }
+        if (more) store_tile(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32);
+    const float inv = 1.0f / l_tot;
+    const int qrow = q0 + r;
+    if (qrow < S) {
+        half_t *op = out + ((long)b * S + qrow) * ldo + h * NH_DH + 4 * hh;
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+            half4 a = {(half_t)(o0[4 * gq] * inv), (half_t)(o0[4 * gq + 1] * inv), (half_t)(o0[4 * gq + 2] * inv),
+                       (half_t)(o0[4 * gq + 3] * inv)};
+            half4 c = {(half_t)(o1[4 * gq] * inv), (half_t)(o1[4 * gq + 1] * inv), (half_t)(o1[4 * gq + 2] * inv),
+                       (half_t)(o1[4 * gq + 3] * inv)};
+            *reinterpret_cast<half4 *>(op + 8 * gq) = a;
+            *reinterpret_cast<half4 *>(op + 32 + 8 * gq) = c;
+        }
+    }
+}
+
+void launch_enc_attention(const half_t *q, const half_t *k, long ld, const half_t *vt, half_t *out, long ldo,
+                          int B, int S, int H, hipStream_t st) {
+    dim3 grid((S + QB - 1) / QB, H, B);
+    hipLaunchKernelGGL(enc_attn_kernel, grid, dim3(256), 0, st, q, k, ld, vt, out, ldo, S, H);
+}

@@ -1,0 +1,82 @@
+// k_elem.hip -- LayerNorm and decoder input embedding (HBM-bound row kernels, gfx950).
+//
+// LayerNorm replaces candle_nn::LayerNorm (eps 1e-5, f32 statistics) at every use inside
+// AudioEncoder / TextDecoder / ResidualAttentionBlock::forward (reached from
+// src/models/whisper/model.rs:455-476).  The residual stream stays f32 in HBM; LayerNorm is the
+// single place where it is rounded to fp16 (the MFMA operand type).  One wavefront per row,
+// 16-byte loads, wavefront-shuffle reductions, no LDS.
+#include "nh_kernels.h"
+
+#define LN_MAXV 5  // d_model <= 1280 -> at most 5 float4 per lane
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                        const float *__restrict__ b, half_t *__restrict__ y,
+                                                        float *__restrict__ y32, int M, int d) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nv = d >> 2;
+    const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + (long)row * d);
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) {
+        int c = lane + 64 * i;
+        v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (c < nv) { v[i] = xr[c]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) {
+        int c = lane + 64 * i;
+        if (c < nv) {
+            f32x4 t = v[i] - mean;
+            s2 += (t[0] * t[0] + t[1] * t[1]) + (t[2] * t[2] + t[3] * t[3]);
+        }
+    }
+    const float inv = 1.0f / sqrtf(wave_sum(s2) / (float)d + 1e-5f);
+    const f32x4 *wr = reinterpret_cast<const f32x4 *>(w), *br = reinterpret_cast<const f32x4 *>(b);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) {
+        int c = lane + 64 * i;
+        if (c < nv) {
+            f32x4 o = (v[i] - mean) * inv * wr[c] + br[c];
+            half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+            *reinterpret_cast<half4 *>(y + (long)row * d + 4 * c) = h;
+            if (y32) *reinterpret_cast<f32x4 *>(y32 + (long)row * d + 4 * c) = o;
+        }
+    }
+}
+
+void launch_layernorm(const float *x, const float *w, const float *b, half_t *y, float *y32, int M, int d,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, w, b, y, y32, M, d);
+}
+
+// TextDecoder::forward input: token_embedding(x) + positional_embedding[0..T]  
+__global__ __launch_bounds__(256) void embed_kernel(const int32_t *__restrict__ tokens, int tok_stride,
+                                                    const half_t *__restrict__ E, const half_t *__restrict__ P,
+                                                    float *__restrict__ x, int Tn, int t0, int d) {
+    const int r = blockIdx.x;  // row = b * Tn + i
+    const int b = r / Tn, i = r - b * Tn;
+    const int tok = tokens[(long)b * tok_stride + t0 + i];
+    const half_t *e = E + (long)tok * d, *p = P + (long)(t0 + i) * d;
+    for (int c = threadIdx.x * 4; c < d; c += 256 * 4) {
+        half4 ev = *reinterpret_cast<const half4 *>(e + c), pv = *reinterpret_cast<const half4 *>(p + c);
+        f32x4 o = {(float)ev[0] + (float)pv[0], (float)ev[1] + (float)pv[1], (float)ev[2] + (float)pv[2],
+                   (float)ev[3] + (float)pv[3]};
+        *reinterpret_cast<f32x4 *>(x + (long)r * d + c) = o;
+    }
+}
+
+void launch_embed(const int32_t *tokens, int tok_stride, const half_t *E, const half_t *P, float *x, int B,
+                  int Tn, int t0, int d, hipStream_t st) {
+    hipLaunchKernelGGL(embed_kernel, dim3(B * Tn), dim3(256), 0, st, tokens, tok_stride, E, P, x, Tn, t0, d);
+}

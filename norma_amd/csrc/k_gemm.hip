@@ -1,0 +1,220 @@
+// k_gemm.hip -- MFMA GEMM for the encoder and the cross-K/V projection (gfx950).
+//
+//   C[M][N] = A[M][K] . W[N][K]^T (+ bias) with fused epilogues; fp16 operands, fp32 accumulate.
+//
+// Replaces, on the reference path, candle's Linear/Conv1d matmuls inside AudioEncoder::forward and
+// the cross-attention key/value projections (reached through Type::encoder_forward /
+// Type::decoder_forward, src/models/whisper/model.rs:455-476).  Conv1d k=3 is expressed as a GEMM
+// whose A rows overlap (lda = stride * channels, K = 3 * channels) -- no im2col buffer.
+//
+// Tile: 128 (M) x 128 (N) x 64 (K) per 256-thread workgroup (4 waves as 2 x 2, 64 x 64 per wave,
+// v_mfma_f32_16x16x32_f16).  Both operands are K-contiguous, so each lane's fragment is one 16-byte
+// LDS read.  LDS image: [128 rows][8 chunks of 16 B], chunk' = chunk ^ ((row >> 1) & 7) (conflict-free
+// ds_read_b128, MI355X LDS banking), double buffered (64 KiB).  Global->LDS goes through registers
+// with the loads of tile t+1 issued before the MFMAs of tile t and written after them.
+//
+// Orientation: by default the weight rows are the MFMA "A" operand, so a lane's 4 accumulator
+// registers are 4 consecutive output COLUMNS of one row -> 8-byte fp16 / 16-byte f32 row-major
+// stores.  The V^T segment uses the other orientation (4 consecutive rows of one column).
+#include "nh_kernels.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (BM * BK * 2)  // 16 KiB per operand tile
+
+__device__ __forceinline__ float gelu_tanh_f(float v) {
+    // 0.5 v (1 + tanh(u)) == v / (1 + exp(-2u)),  u = sqrt(2/pi) v (1 + 0.044715 v^2)
+    float u = 0.7978845608028654f * v * (1.0f + 0.044715f * v * v);
+    return v / (1.0f + __expf(-2.0f * u));
+}
+
+__device__ __forceinline__ const half_t *a_row_ptr(const GemmParams &p, int m) {
+    if (m >= p.M) m = p.M - 1;  // clamp: tail rows are loaded but never stored
+    int b = m / p.a_rpb, r = m - b * p.a_rpb;
+    return p.A + (long)b * p.a_bstride + (long)r * p.lda;
+}
+
+template <bool SWAP>
+__device__ __forceinline__ void gemm_mainloop(const GemmParams &p, char *smem, int m0, int n0,
+                                              f32x4 (&acc)[4][4]) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    // staging map: slot s = tid + 256 i (i = 0..3): row = s >> 3, chunk' = s & 7 (tid & 7 for all i)
+    const int cq = tid & 7;
+    const half_t *ag[4], *wg[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        int row = (tid >> 3) + 32 * i;
+        int c = cq ^ ((row >> 1) & 7);
+        ag[i] = a_row_ptr(p, m0 + row) + c * 8;
+        int n = n0 + row;  // N is a multiple of BN
+        wg[i] = p.W + (long)n * p.K + c * 8;
+    }
+    const int nt = p.K / BK;
+    u32x4 ra[4], rb[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        ra[i] = *reinterpret_cast<const u32x4 *>(ag[i]);
+        rb[i] = *reinterpret_cast<const u32x4 *>(wg[i]);
+    }
+    {
+        u32x4 *la = reinterpret_cast<u32x4 *>(smem), *lb = reinterpret_cast<u32x4 *>(smem + TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < 4; i++) { la[tid + 256 * i] = ra[i]; lb[tid + 256 * i] = rb[i]; }
+    }
+    __syncthreads();
+    // fragment read offsets (bytes within a tile): row r, chunk 4*ks + (lane>>4), swizzled
+    const int fr = lane & 15, fq = lane >> 4;
+    int offA[4], offB[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int rowA = wm * 64 + 16 * j + fr;  // activation rows (m)
+        int rowB = wn * 64 + 16 * j + fr;  // weight rows (n)
+        offA[j] = rowA * 128 + ((fq ^ ((rowA >> 1) & 7)) << 4);
+        offB[j] = rowB * 128 + ((fq ^ ((rowB >> 1) & 7)) << 4);
+    }
+    int cur = 0;
+    for (int t = 0; t < nt; t++) {
+        const bool more = (t + 1 < nt);
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                ra[i] = *reinterpret_cast<const u32x4 *>(ag[i] + (long)(t + 1) * BK);
+                rb[i] = *reinterpret_cast<const u32x4 *>(wg[i] + (long)(t + 1) * BK);
+            }
+        }
+        const char *ta = smem + cur * 2 * TILE_BYTES, *tb = ta + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            half8 fa[4], fb[4];
+            // chunk index 4*ks + fq; the xor only touches the low 3 bits, and (4*ks) flips bit 2:
+            // (4ks + fq) ^ g == (fq ^ g) ^ (4ks) because fq < 4 -> byte offset ^ (ks << 6)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                fa[j] = *reinterpret_cast<const half8 *>(ta + (offA[j] ^ (ks << 6)));
+                fb[j] = *reinterpret_cast<const half8 *>(tb + (offB[j] ^ (ks << 6)));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (SWAP)  // D[row = n (weights)][col = m (activations)]
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[i], fa[j], acc[i][j], 0, 0, 0);
+                    else       // D[row = m][col = n]
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[j], fb[i], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) {
+            u32x4 *la = reinterpret_cast<u32x4 *>(smem + (cur ^ 1) * 2 * TILE_BYTES);
+            u32x4 *lb = reinterpret_cast<u32x4 *>(smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { la[tid + 256 * i] = ra[i]; lb[tid + 256 * i] = rb[i]; }
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+}
+
+__device__ __forceinline__ long out_row(const GemmParams &p, int m) {
+    int b = m / p.o_rpb, r = m - b * p.o_rpb;
+    return (long)b * p.o_bstride + r + p.o_off;
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    // XCD-aware tile order: blocks b and b+8 share an XCD (L2); give each XCD a contiguous run of
+    // tiles so the N-tiles of one M-panel (same A rows) are neighbours in one L2.
+    const int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
+    const int nwg = ntn * ntm;
+    int bid = blockIdx.x;
+    {
+        int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = bid / ntn, tn = bid - tm * ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = w >> 1, wn = w & 1;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int seg = (p.epi == EPI_F16 || p.epi == EPI_GELU_F16) ? n0 / p.seg_n : 0;
+    const bool vt = (p.epi == EPI_F16 && seg == p.vt_seg);
+    if (vt) gemm_mainloop<false>(p, smem, m0, n0, acc);
+    else gemm_mainloop<true>(p, smem, m0, n0, acc);
+
+    if (vt) {
+        // lane holds rows m = mb + 4 fq + r (r = 0..3) of column n = nb + fr
+        half_t *dst = reinterpret_cast<half_t *>(seg == 0 ? p.out[0] : seg == 1 ? p.out[1] : p.out[2]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int n = n0 + wn * 64 + 16 * i + fr;
+            float bv = p.bias ? p.bias[n] : 0.f;
+            int nl = n - seg * p.seg_n, h = nl >> 6, dh = nl & 63;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                int m = m0 + wm * 64 + 16 * j + 4 * fq;
+                if (m >= p.M) continue;
+                int b = m / p.S, s = m - b * p.S;
+                half_t *row = dst + ((long)(b * p.H + h) * NH_DH + dh) * NH_SP;
+                if (s + 3 < p.S && m + 3 < p.M) {
+                    half4 v = {(half_t)(acc[i][j][0] + bv), (half_t)(acc[i][j][1] + bv),
+                               (half_t)(acc[i][j][2] + bv), (half_t)(acc[i][j][3] + bv)};
+                    *reinterpret_cast<half4 *>(row + s) = v;
+                } else {
+                    for (int r = 0; r < 4; r++) {
+                        int mm = m + r;
+                        if (mm >= p.M) break;
+                        int bb = mm / p.S, ss = mm - bb * p.S;
+                        dst[((long)(bb * p.H + h) * NH_DH + dh) * NH_SP + ss] = (half_t)(acc[i][j][r] + bv);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    half_t *obase = reinterpret_cast<half_t *>(seg == 0 ? p.out[0] : seg == 1 ? p.out[1] : p.out[2]);
+    // SWAP orientation: lane holds columns n = nb + 4 fq + r (r = 0..3) of row m = mb + fr
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int n = n0 + wn * 64 + 16 * i + 4 * fq;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4 *>(p.bias + n);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int m = m0 + wm * 64 + 16 * j + fr;
+            if (m >= p.M) continue;
+            f32x4 v = acc[i][j] + bv;
+            if (p.epi == EPI_F16 || p.epi == EPI_GELU_F16) {
+                if (p.epi == EPI_GELU_F16) {
+                    v[0] = gelu_tanh_f(v[0]); v[1] = gelu_tanh_f(v[1]);
+                    v[2] = gelu_tanh_f(v[2]); v[3] = gelu_tanh_f(v[3]);
+                }
+                half_t *dst = obase + out_row(p, m) * p.ldo + (n - seg * p.seg_n);
+                half4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *reinterpret_cast<half4 *>(dst) = hv;
+            } else if (p.epi == EPI_RESID_F32) {
+                float *dst = reinterpret_cast<float *>(p.out[0]) + (long)m * p.ldo + n;
+                f32x4 x = *reinterpret_cast<const f32x4 *>(dst);
+                *reinterpret_cast<f32x4 *>(dst) = x + v;
+            } else {  // EPI_CONV2_F32
+                int s = m % p.S;
+                f32x4 pe = *reinterpret_cast<const f32x4 *>(p.pos + (long)s * p.N + n);
+                f32x4 o = {gelu_tanh_f(v[0]) + pe[0], gelu_tanh_f(v[1]) + pe[1], gelu_tanh_f(v[2]) + pe[2],
+                           gelu_tanh_f(v[3]) + pe[3]};
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out[0]) + (long)m * p.ldo + n) = o;
+            }
+        }
+    }
+}
+
+void launch_gemm(const GemmParams &p, hipStream_t st) {
+    int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
+    hipLaunchKernelGGL(gemm_f16_kernel, dim3(ntn * ntm), dim3(256), 0, st, p);
+}

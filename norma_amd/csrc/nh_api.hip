@@ -1,0 +1,814 @@
+// nh_api.hip -- implementation of the C ABI declared in include/norma_hip.h.
+//
+// Owns the device state of one Whisper model on one MI355X (weights in fp16, f32 LayerNorm/bias
+// parameters, activation workspaces sized for `max_batch` 30-second clips) and sequences the gfx950
+// kernels on one HIP stream.  No torch, no candle, no CPU fallback: every entry point either runs
+// the HIP path or returns an error.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/norma_hip.h"
+#include "nh_kernels.h"
+
+#define HIPCHK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            return ctx->fail(NH_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+        }                                                                                     \
+    } while (0)
+
+static std::string g_create_error;
+
+struct LinW { half_t *w = nullptr; float *b = nullptr; };
+struct LnW { float *w = nullptr, *b = nullptr; };
+struct EncLayer { LnW ln1, ln2; LinW qkv, o, fc1, fc2; };
+struct DecLayer { LnW ln1, ln2, ln3; LinW qkv, o, cq, ckv, co, fc1, fc2; half_t *ck = nullptr, *cv = nullptr, *sk = nullptr, *sv = nullptr; };
+
+struct nh_ctx {
+    int dev = 0;
+    hipStream_t st = nullptr;
+    nh_config c{};
+    int B = 1;
+    std::string err;
+    std::vector<void *> allocs;
+    // weights
+    LinW conv1, conv2;
+    float *enc_pos = nullptr;
+    std::vector<EncLayer> enc;
+    LnW ln_post, dec_ln;
+    half_t *tok_emb = nullptr, *dec_pos = nullptr;
+    std::vector<DecLayer> dec;
+    std::set<std::string> expected, loaded;
+    // mel
+    MelTables mt{};
+    int32_t *mel_grp = nullptr;
+    bool have_filters = false;
+    float *pcm = nullptr;
+    int32_t *nsamp = nullptr;
+    float *mel32 = nullptr;
+    unsigned *chunk_max = nullptr;
+    half_t *mel_img = nullptr;
+    // encoder workspaces
+    half_t *h1 = nullptr, *xn = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr, *att = nullptr, *hid = nullptr,
+           *xa16 = nullptr;
+    float *x = nullptr, *xa32 = nullptr;
+    // decoder workspaces
+    float *dx = nullptr, *dy32 = nullptr, *logits = nullptr;
+    half_t *dxn = nullptr, *dq = nullptr, *datt = nullptr, *dhid = nullptr;
+    DecodeState ds{};
+    uint8_t *suppress = nullptr;
+    RuleTokens tk{};
+    bool have_tokens = false;
+    int VP = 0;
+    // pinned host staging
+    int32_t *h_done = nullptr;
+    // state
+    int cur_batch = 0, frames = 0, S = 0, last_frames = -1;
+    bool have_mel = false, have_enc = false;
+    // timings
+    hipEvent_t ev[7]{};
+    nh_timings tm{};
+    bool profile_gemm = false;
+    std::vector<hipEvent_t> gemm_ev;
+    size_t gemm_ev_used = 0;
+    double gemm_flops_acc = 0.0;
+
+    int fail(int code, const std::string &msg) { err = msg; return code; }
+};
+
+template <typename T>
+static T *dalloc(nh_ctx *ctx, size_t n, bool zero = true) {
+    void *p = nullptr;
+    if (n == 0) n = 1;
+    if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
+    if (zero) hipMemset(p, 0, n * sizeof(T));
+    ctx->allocs.push_back(p);
+    return reinterpret_cast<T *>(p);
+}
+
+// ---- expected tensor names (the set candle reads) ---------------------------------
+static void add_lin(std::set<std::string> &s, const std::string &p, bool bias = true) {
+    s.insert(p + ".weight");
+    if (bias) s.insert(p + ".bias");
+}
+static void add_attn(std::set<std::string> &s, const std::string &p) {
+    add_lin(s, p + ".q_proj"); add_lin(s, p + ".k_proj", false); add_lin(s, p + ".v_proj"); add_lin(s, p + ".out_proj");
+}
+static void build_expected(nh_ctx *ctx) {
+    auto &s = ctx->expected;
+    add_lin(s, "model.encoder.conv1"); add_lin(s, "model.encoder.conv2");
+    for (int i = 0; i < ctx->c.encoder_layers; i++) {
+        std::string p = "model.encoder.layers." + std::to_string(i);
+        add_attn(s, p + ".self_attn"); add_lin(s, p + ".self_attn_layer_norm");
+        add_lin(s, p + ".fc1"); add_lin(s, p + ".fc2"); add_lin(s, p + ".final_layer_norm");
+    }
+    add_lin(s, "model.encoder.layer_norm");
+    s.insert("model.decoder.embed_tokens.weight"); s.insert("model.decoder.embed_positions.weight");
+    for (int i = 0; i < ctx->c.decoder_layers; i++) {
+        std::string p = "model.decoder.layers." + std::to_string(i);
+        add_attn(s, p + ".self_attn"); add_lin(s, p + ".self_attn_layer_norm");
+        add_attn(s, p + ".encoder_attn"); add_lin(s, p + ".encoder_attn_layer_norm");
+        add_lin(s, p + ".fc1"); add_lin(s, p + ".fc2"); add_lin(s, p + ".final_layer_norm");
+    }
+    add_lin(s, "model.decoder.layer_norm");
+}
+
+static long mel_frames_for(long n) {  // candle pcm_to_mel frame count (SURVEY.md 3.3[A]-2)
+    long n_len = n / 160, pad = 1500;
+    if (n_len % pad != 0) n_len = (n_len / pad + 1) * pad;
+    return n_len + pad;
+}
+
+extern "C" int nh_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" const char *nh_last_error(const nh_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" void nh_destroy(nh_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->dev);
+    if (ctx->st) hipStreamSynchronize(ctx->st);
+    for (void *p : ctx->allocs) hipFree(p);
+    if (ctx->h_done) hipHostFree(ctx->h_done);
+    for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
+    for (auto &e : ctx->gemm_ev) hipEventDestroy(e);
+    if (ctx->st) hipStreamDestroy(ctx->st);
+    delete ctx;
+}
+
+static int build_mel_tables(nh_ctx *ctx) {
+    // host tables with libm, the same f32 expressions candle evaluates (see k_mel.hip)
+    std::vector<float> hann(400), dc(625), dsn(625), twc(375), tws(375);
+    const float two_pi = (float)M_PI + (float)M_PI;
+    for (int i = 0; i < 400; i++) hann[i] = 0.5f * (1.0f - cosf((two_pi * (float)i) / 400.0f));
+    for (int k = 0; k < 25; k++)
+        for (int j = 0; j < 25; j++) {
+            float angle = two_pi * (float)k * (float)j / 25.0f;
+            dc[k * 25 + j] = cosf(angle); dsn[k * 25 + j] = sinf(angle);
+        }
+    int off = 0;
+    for (int h = 25; h <= 200; h *= 2) {
+        float n_t = (float)(2 * h);
+        for (int k = 0; k < h; k++) {
+            float theta = two_pi * (float)k / n_t;
+            twc[off + k] = cosf(theta); tws[off + k] = -sinf(theta);
+        }
+        off += h;
+    }
+    float *d_h = dalloc<float>(ctx, 400), *d_dc = dalloc<float>(ctx, 625), *d_ds = dalloc<float>(ctx, 625);
+    float *d_tc = dalloc<float>(ctx, 375), *d_ts = dalloc<float>(ctx, 375);
+    if (!d_h || !d_dc || !d_ds || !d_tc || !d_ts) return ctx->fail(NH_ERR_NOMEM, "hipMalloc(mel tables)");
+    HIPCHK(hipMemcpy(d_h, hann.data(), 400 * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_dc, dc.data(), 625 * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_ds, dsn.data(), 625 * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_tc, twc.data(), 375 * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d_ts, tws.data(), 375 * 4, hipMemcpyHostToDevice));
+    ctx->mt.hann = d_h; ctx->mt.dft_cos = d_dc; ctx->mt.dft_sin = d_ds; ctx->mt.tw_cos = d_tc; ctx->mt.tw_sin = d_ts;
+    return NH_OK;
+}
+
+extern "C" int nh_create(int device_ordinal, const nh_config *cfg, int max_batch, nh_ctx **out) {
+    if (!cfg || !out || max_batch < 1) { g_create_error = "nh_create: bad arguments"; return NH_ERR_INVALID; }
+    const int d = cfg->d_model;
+    if (d % 128 != 0 || d > 1280 || d / cfg->encoder_attention_heads != NH_DH ||
+        d / cfg->decoder_attention_heads != NH_DH || cfg->max_source_positions != 1500 ||
+        (cfg->num_mel_bins != 80 && cfg->num_mel_bins != 128) || max_batch > 64) {
+        g_create_error = "nh_create: unsupported config (need d_model % 128 == 0, d_model <= 1280, head dim 64, "
+                         "max_source_positions 1500, num_mel_bins 80|128, max_batch <= 64)";
+        return NH_ERR_INVALID;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_ordinal < 0 || device_ordinal >= ndev) {
+        g_create_error = "nh_create: no HIP device with ordinal " + std::to_string(device_ordinal) +
+                         " (SelectedDevice::Rocm needs a visible MI355X; there is no CPU fallback)";
+        return NH_ERR_HIP;
+    }
+    nh_ctx *ctx = new nh_ctx();
+    ctx->dev = device_ordinal; ctx->c = *cfg; ctx->B = max_batch;
+    auto bail = [&](int code) { g_create_error = ctx->err; nh_destroy(ctx); return code; };
+    if (hipSetDevice(device_ordinal) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(NH_ERR_HIP); }
+    if (hipStreamCreate(&ctx->st) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(NH_ERR_HIP); }
+    for (auto &e : ctx->ev) hipEventCreate(&e);
+    build_expected(ctx);
+    const int B = max_batch, V = cfg->vocab_size, nm = cfg->num_mel_bins, ctxlen = cfg->max_target_positions;
+    const long M = (long)B * 1500;
+    ctx->VP = (V + 63) & ~63;
+    bool ok = true;
+#define DA(field, T, n) ok = ok && ((ctx->field = dalloc<T>(ctx, (size_t)(n))) != nullptr)
+    // weights
+    DA(conv1.w, half_t, (long)d * 3 * NH_MELP); DA(conv1.b, float, d);
+    DA(conv2.w, half_t, (long)d * 3 * d); DA(conv2.b, float, d);
+    DA(enc_pos, float, 1500L * d);
+    ctx->enc.resize(cfg->encoder_layers);
+    for (auto &L : ctx->enc) {
+#define DL(f, T, n) ok = ok && ((L.f = dalloc<T>(ctx, (size_t)(n))) != nullptr)
+        DL(ln1.w, float, d); DL(ln1.b, float, d); DL(ln2.w, float, d); DL(ln2.b, float, d);
+        DL(qkv.w, half_t, 3L * d * d); DL(qkv.b, float, 3 * d); DL(o.w, half_t, (long)d * d); DL(o.b, float, d);
+        DL(fc1.w, half_t, 4L * d * d); DL(fc1.b, float, 4 * d); DL(fc2.w, half_t, 4L * d * d); DL(fc2.b, float, d);
+    }
+    DA(ln_post.w, float, d); DA(ln_post.b, float, d); DA(dec_ln.w, float, d); DA(dec_ln.b, float, d);
+    DA(tok_emb, half_t, (long)V * d); DA(dec_pos, half_t, (long)ctxlen * d);
+    ctx->dec.resize(cfg->decoder_layers);
+    for (auto &L : ctx->dec) {
+        DL(ln1.w, float, d); DL(ln1.b, float, d); DL(ln2.w, float, d); DL(ln2.b, float, d); DL(ln3.w, float, d); DL(ln3.b, float, d);
+        DL(qkv.w, half_t, 3L * d * d); DL(qkv.b, float, 3 * d); DL(o.w, half_t, (long)d * d); DL(o.b, float, d);
+        DL(cq.w, half_t, (long)d * d); DL(cq.b, float, d); DL(ckv.w, half_t, 2L * d * d); DL(ckv.b, float, 2 * d);
+        DL(co.w, half_t, (long)d * d); DL(co.b, float, d);
+        DL(fc1.w, half_t, 4L * d * d); DL(fc1.b, float, 4 * d); DL(fc2.w, half_t, 4L * d * d); DL(fc2.b, float, d);
+        DL(ck, half_t, M * d); DL(cv, half_t, M * d);
+        DL(sk, half_t, (long)B * ctxlen * d); DL(sv, half_t, (long)B * ctxlen * d);
+#undef DL
+    }
+    // mel
+    DA(pcm, float, (long)B * NH_N_SAMPLES); DA(nsamp, int32_t, B); DA(mel32, float, (long)B * nm * NH_N_FRAMES);
+    DA(chunk_max, unsigned, B); DA(mel_img, half_t, (long)B * (NH_N_FRAMES + 2) * NH_MELP);
+    DA(mel_grp, int32_t, 2 * nm);
+    // encoder
+    DA(h1, half_t, (long)B * (NH_N_FRAMES + 2) * d); DA(x, float, M * d); DA(xn, half_t, M * d);
+    DA(q, half_t, M * d); DA(k, half_t, M * d); DA(vt, half_t, (long)B * d * NH_SP); DA(att, half_t, M * d);
+    DA(hid, half_t, M * 4 * d); DA(xa16, half_t, M * d); DA(xa32, float, M * d);
+    // decoder
+    DA(dx, float, (long)B * d); DA(dy32, float, (long)B * d); DA(logits, float, (long)B * ctx->VP);
+    DA(dxn, half_t, (long)B * d); DA(dq, half_t, (long)B * d); DA(datt, half_t, (long)B * d); DA(dhid, half_t, (long)B * 4 * d);
+    DA(ds.tokens, int32_t, (long)B * ctxlen); DA(ds.n_tokens, int32_t, B); DA(ds.done, int32_t, B);
+    DA(ds.have_last, int32_t, B); DA(ds.last_ts, int32_t, B); DA(ds.sum_logprob, double, B); DA(ds.no_speech, double, B);
+    DA(ds.n_active, int32_t, 1); DA(suppress, uint8_t, V);
+#undef DA
+    if (!ok) { ctx->err = "hipMalloc failed while sizing the context (out of device memory?)"; return bail(NH_ERR_NOMEM); }
+    ctx->ds.suppress = ctx->suppress;
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_done), sizeof(int32_t) * 64, 0) != hipSuccess) {
+        ctx->err = "hipHostMalloc failed"; return bail(NH_ERR_NOMEM);
+    }
+    {   // encoder sinusoids, recomputed in f32 exactly as candle's sinusoids()
+        std::vector<float> pos(1500L * d);
+        int half = d / 2;
+        float inc = logf(10000.0f) / (float)(half - 1);
+        for (int p = 0; p < 1500; p++)
+            for (int i = 0; i < half; i++) {
+                float st = (float)p * expf((float)i * (-inc));
+                pos[(long)p * d + i] = sinf(st);
+                pos[(long)p * d + half + i] = cosf(st);
+            }
+        if (hipMemcpy(ctx->enc_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            ctx->err = "hipMemcpy(enc_pos) failed"; return bail(NH_ERR_HIP);
+        }
+    }
+    int rc = build_mel_tables(ctx);
+    if (rc != NH_OK) return bail(rc);
+    *out = ctx;
+    return NH_OK;
+}
+
+// ---- weight loading ----------------------------------------------------------------------------------
+static float host_elem(const void *data, int dtype, size_t i) {
+    return dtype == NH_DTYPE_F32 ? reinterpret_cast<const float *>(data)[i]
+                                 : (float)reinterpret_cast<const _Float16 *>(data)[i];
+}
+static int up_f16(nh_ctx *ctx, half_t *dst, const void *data, int dtype, size_t n) {
+    if (dtype == NH_DTYPE_F16) { HIPCHK(hipMemcpy(dst, data, n * 2, hipMemcpyHostToDevice)); return NH_OK; }
+    std::vector<_Float16> tmp(n);
+    const float *s = reinterpret_cast<const float *>(data);
+    for (size_t i = 0; i < n; i++) tmp[i] = (_Float16)s[i];
+    HIPCHK(hipMemcpy(dst, tmp.data(), n * 2, hipMemcpyHostToDevice));
+    return NH_OK;
+}
+static int up_f32(nh_ctx *ctx, float *dst, const void *data, int dtype, size_t n) {
+    if (dtype == NH_DTYPE_F32) { HIPCHK(hipMemcpy(dst, data, n * 4, hipMemcpyHostToDevice)); return NH_OK; }
+    std::vector<float> tmp(n);
+    for (size_t i = 0; i < n; i++) tmp[i] = host_elem(data, dtype, i);
+    HIPCHK(hipMemcpy(dst, tmp.data(), n * 4, hipMemcpyHostToDevice));
+    return NH_OK;
+}
+// conv weight [co][ci][3] -> [co][kk * cpad + ci] fp16 (zero padded channels)
+static int up_conv(nh_ctx *ctx, half_t *dst, const void *data, int dtype, int co, int ci, int cpad) {
+    std::vector<_Float16> tmp((size_t)co * 3 * cpad, (_Float16)0.f);
+    for (int o = 0; o < co; o++)
+        for (int c = 0; c < ci; c++)
+            for (int kk = 0; kk < 3; kk++)
+                tmp[((size_t)o * 3 + kk) * cpad + c] = (_Float16)host_elem(data, dtype, ((size_t)o * ci + c) * 3 + kk);
+    HIPCHK(hipMemcpy(dst, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+    return NH_OK;
+}
+
+static bool starts(const std::string &s, const char *p, std::string &rest) {
+    size_t n = strlen(p);
+    if (s.compare(0, n, p) != 0) return false;
+    rest = s.substr(n);
+    return true;
+}
+
+extern "C" int nh_load_tensor(nh_ctx *ctx, const char *name_c, int dtype, const int64_t *shape, int ndim,
+                              const void *data) {
+    if (!ctx || !name_c || !data || !shape || (dtype != NH_DTYPE_F32 && dtype != NH_DTYPE_F16))
+        return ctx ? ctx->fail(NH_ERR_INVALID, "nh_load_tensor: bad arguments") : NH_ERR_INVALID;
+    hipSetDevice(ctx->dev);
+    const std::string name(name_c);
+    if (name == "model.encoder.embed_positions.weight" || name == "proj_out.weight") return NH_OK;  // not read by candle
+    if (!ctx->expected.count(name)) return ctx->fail(NH_ERR_INVALID, "nh_load_tensor: unknown tensor name " + name);
+    size_t n = 1;
+    for (int i = 0; i < ndim; i++) n *= (size_t)shape[i];
+    const int d = ctx->c.d_model;
+    auto want = [&](size_t expect) -> int {
+        if (n != expect)
+            return ctx->fail(NH_ERR_INVALID, "nh_load_tensor: " + name + " has " + std::to_string(n) +
+                                                 " elements, expected " + std::to_string(expect));
+        return NH_OK;
+    };
+    int rc = NH_OK;
+    std::string rest;
+    auto lin = [&](LinW &L, const std::string &leaf, size_t n_out, size_t n_in, size_t row_off) -> int {
+        if (leaf == "weight") { if ((rc = want(n_out * n_in))) return rc; return up_f16(ctx, L.w + row_off * n_in, data, dtype, n); }
+        if (leaf == "bias") { if ((rc = want(n_out))) return rc; return up_f32(ctx, L.b + row_off, data, dtype, n); }
+        return ctx->fail(NH_ERR_INVALID, "nh_load_tensor: unknown leaf in " + name);
+    };
+    auto ln = [&](LnW &L, const std::string &leaf) -> int {
+        if ((rc = want(d))) return rc;
+        if (leaf == "weight") return up_f32(ctx, L.w, data, dtype, n);
+        if (leaf == "bias") return up_f32(ctx, L.b, data, dtype, n);
+        return ctx->fail(NH_ERR_INVALID, "nh_load_tensor: unknown leaf in " + name);
+    };
+    if (name == "model.encoder.conv1.weight") { if (!(rc = want((size_t)d * ctx->c.num_mel_bins * 3))) rc = up_conv(ctx, ctx->conv1.w, data, dtype, d, ctx->c.num_mel_bins, NH_MELP); }
+    else if (name == "model.encoder.conv1.bias") { if (!(rc = want(d))) rc = up_f32(ctx, ctx->conv1.b, data, dtype, n); }
+    else if (name == "model.encoder.conv2.weight") { if (!(rc = want((size_t)d * d * 3))) rc = up_conv(ctx, ctx->conv2.w, data, dtype, d, d, d); }
+    else if (name == "model.encoder.conv2.bias") { if (!(rc = want(d))) rc = up_f32(ctx, ctx->conv2.b, data, dtype, n); }
+    else if (starts(name, "model.encoder.layer_norm.", rest)) rc = ln(ctx->ln_post, rest);
+    else if (starts(name, "model.decoder.layer_norm.", rest)) rc = ln(ctx->dec_ln, rest);
+    else if (name == "model.decoder.embed_tokens.weight") { if (!(rc = want((size_t)ctx->c.vocab_size * d))) rc = up_f16(ctx, ctx->tok_emb, data, dtype, n); }
+    else if (name == "model.decoder.embed_positions.weight") { if (!(rc = want((size_t)ctx->c.max_target_positions * d))) rc = up_f16(ctx, ctx->dec_pos, data, dtype, n); }
+    else {
+        bool is_enc = starts(name, "model.encoder.layers.", rest);
+        bool is_dec = !is_enc && starts(name, "model.decoder.layers.", rest);
+        if (!is_enc && !is_dec) return ctx->fail(NH_ERR_INVALID, "nh_load_tensor: unhandled tensor " + name);
+        size_t dot = rest.find('.');
+        int idx = atoi(rest.substr(0, dot).c_str());
+        std::string sub = rest.substr(dot + 1), leaf;
+        if (is_enc) {
+            EncLayer &L = ctx->enc[idx];
+            if (starts(sub, "self_attn.q_proj.", leaf)) rc = lin(L.qkv, leaf, d, d, 0);
+            else if (starts(sub, "self_attn.k_proj.", leaf)) rc = lin(L.qkv, leaf, d, d, d);
+            else if (starts(sub, "self_attn.v_proj.", leaf)) rc = lin(L.qkv, leaf, d, d, 2 * d);
+            else if (starts(sub, "self_attn.out_proj.", leaf)) rc = lin(L.o, leaf, d, d, 0);
+            else if (starts(sub, "self_attn_layer_norm.", leaf)) rc = ln(L.ln1, leaf);
+            else if (starts(sub, "fc1.", leaf)) rc = lin(L.fc1, leaf, 4 * d, d, 0);
+            else if (starts(sub, "fc2.", leaf)) rc = lin(L.fc2, leaf, d, 4 * d, 0);
+            else if (starts(sub, "final_layer_norm.", leaf)) rc = ln(L.ln2, leaf);
+            else return ctx->fail(NH_ERR_INVALID, "nh_load_tensor: unhandled tensor " + name);
+        } else {
+            DecLayer &L = ctx->dec[idx];
+            if (starts(sub, "self_attn.q_proj.", leaf)) rc = lin(L.qkv, leaf, d, d, 0);
+            else if (starts(sub, "self_attn.k_proj.", leaf)) rc = lin(L.qkv, leaf, d, d, d);
+            else if (starts(sub, "self_attn.v_proj.", leaf)) rc = lin(L.qkv, leaf, d, d, 2 * d);
+            else if (starts(sub, "self_attn.out_proj.", leaf)) rc = lin(L.o, leaf, d, d, 0);
+            else if (starts(sub, "self_attn_layer_norm.", leaf)) rc = ln(L.ln1, leaf);
+            else if (starts(sub, "encoder_attn.q_proj.", leaf)) rc = lin(L.cq, leaf, d, d, 0);
+            else if (starts(sub, "encoder_attn.k_proj.", leaf)) rc = lin(L.ckv, leaf, d, d, 0);
+            else if (starts(sub, "encoder_attn.v_proj.", leaf)) rc = lin(L.ckv, leaf, d, d, d);
+            else if (starts(sub, "encoder_attn.out_proj.", leaf)) rc = lin(L.co, leaf, d, d, 0);
+            else if (starts(sub, "encoder_attn_layer_norm.", leaf)) rc = ln(L.ln2, leaf);
+            else if (starts(sub, "fc1.", leaf)) rc = lin(L.fc1, leaf, 4 * d, d, 0);
+            else if (starts(sub, "fc2.", leaf)) rc = lin(L.fc2, leaf, d, 4 * d, 0);
+            else if (starts(sub, "final_layer_norm.", leaf)) rc = ln(L.ln3, leaf);
+            else return ctx->fail(NH_ERR_INVALID, "nh_load_tensor: unhandled tensor " + name);
+        }
+    }
+    if (rc == NH_OK) ctx->loaded.insert(name);
+    return rc;
+}
+
+extern "C" int nh_missing_tensors(const nh_ctx *ctx) {
+    return ctx ? (int)(ctx->expected.size() - ctx->loaded.size()) : -1;
+}
+
+extern "C" int nh_set_mel_filters(nh_ctx *ctx, const float *filters, int n_mel) {
+    if (!ctx || !filters) return NH_ERR_INVALID;
+    if (n_mel != ctx->c.num_mel_bins) return ctx->fail(NH_ERR_INVALID, "Unexpected number of mel bins (num_mel_bins), got: " + std::to_string(n_mel));
+    hipSetDevice(ctx->dev);
+    float *df = dalloc<float>(ctx, (size_t)n_mel * 201);
+    if (!df) return ctx->fail(NH_ERR_NOMEM, "hipMalloc(mel filters)");
+    HIPCHK(hipMemcpy(df, filters, (size_t)n_mel * 201 * 4, hipMemcpyHostToDevice));
+    std::vector<int32_t> grp(2 * n_mel);
+    for (int m = 0; m < n_mel; m++) {
+        int g0 = 50, g1 = 0;
+        for (int g = 0; g < 50; g++) {
+            bool nz = false;
+            for (int k = 4 * g; k < 4 * g + 4; k++) nz = nz || filters[(size_t)m * 201 + k] != 0.f;
+            if (nz) { if (g < g0) g0 = g; g1 = g + 1; }
+        }
+        if (g0 > g1) g0 = g1 = 0;
+        grp[2 * m] = g0; grp[2 * m + 1] = g1;
+    }
+    HIPCHK(hipMemcpy(ctx->mel_grp, grp.data(), grp.size() * 4, hipMemcpyHostToDevice));
+    ctx->mt.filters = df;
+    ctx->have_filters = true;
+    return NH_OK;
+}
+
+extern "C" int nh_set_tokens(nh_ctx *ctx, const nh_tokens *tk, const int32_t *suppress_tokens, int n_suppress) {
+    if (!ctx || !tk || (n_suppress > 0 && !suppress_tokens)) return NH_ERR_INVALID;
+    const int V = ctx->c.vocab_size;
+    auto inr = [&](int t) { return t >= 0 && t < V; };
+    if (!inr(tk->sot) || !inr(tk->eot) || !inr(tk->task) || !inr(tk->no_speech) || !inr(tk->no_timestamps) ||
+        !inr(tk->zero_sec) || !inr(tk->one_sec) || (tk->lang >= V))
+        return ctx->fail(NH_ERR_INVALID, "nh_set_tokens: token id outside the vocabulary");
+    hipSetDevice(ctx->dev);
+    // monolingual.rs:386-395: suppress_tokens = config list U {no_timestamps}
+    std::vector<uint8_t> sup(V, 0);
+    for (int i = 0; i < n_suppress; i++) if (inr(suppress_tokens[i])) sup[suppress_tokens[i]] = 1;
+    sup[tk->no_timestamps] = 1;
+    HIPCHK(hipMemcpy(ctx->suppress, sup.data(), V, hipMemcpyHostToDevice));
+    ctx->tk = RuleTokens{tk->sot, tk->eot, tk->lang, tk->task, tk->no_speech, tk->no_timestamps, tk->zero_sec, tk->one_sec};
+    ctx->have_tokens = true;
+    return NH_OK;
+}
+
+// ---- log-mel -------------------------------------------------------------------------------------------
+static int prepare_batch(nh_ctx *ctx, const int32_t *n_samples, int batch) {
+    if (batch < 1 || batch > ctx->B) return ctx->fail(NH_ERR_INVALID, "batch must be in [1, max_batch]");
+    long fr = -1;
+    for (int b = 0; b < batch; b++) {
+        if (n_samples[b] < 1 || n_samples[b] > NH_N_SAMPLES)
+            return ctx->fail(NH_ERR_INVALID, "clip length must be in [1, 480000] samples");
+        long f = mel_frames_for(n_samples[b]);
+        if (f > NH_N_FRAMES) f = NH_N_FRAMES;  // narrow(2, 0, min(3000, frames)), model.rs:88
+        if (fr < 0) fr = f;
+        else if (fr != f) return ctx->fail(NH_ERR_INVALID, "clips of one batch must produce the same number of mel frames");
+    }
+    ctx->cur_batch = batch; ctx->frames = (int)fr; ctx->S = (int)((fr + 2 - 3) / 2 + 1);
+    ctx->have_mel = false; ctx->have_enc = false;
+    if (ctx->frames != ctx->last_frames) {  // the zero rows framing each clip move with the frame count
+        HIPCHK(hipMemsetAsync(ctx->mel_img, 0, sizeof(half_t) * (size_t)ctx->B * (NH_N_FRAMES + 2) * NH_MELP, ctx->st));
+        HIPCHK(hipMemsetAsync(ctx->h1, 0, sizeof(half_t) * (size_t)ctx->B * (NH_N_FRAMES + 2) * ctx->c.d_model, ctx->st));
+        ctx->last_frames = ctx->frames;
+    }
+    return NH_OK;
+}
+
+static int run_logmel(nh_ctx *ctx, const float *pcm_dev, const int32_t *n_samples, int64_t stride, int batch) {
+    if (!ctx->have_filters) return ctx->fail(NH_ERR_STATE, "nh_logmel: mel filters not set");
+    int rc = prepare_batch(ctx, n_samples, batch);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(ctx->nsamp, n_samples, sizeof(int32_t) * batch, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipEventRecord(ctx->ev[0], ctx->st));
+    HIPCHK(hipMemsetAsync(ctx->chunk_max, 0, sizeof(unsigned) * batch, ctx->st));
+    launch_logmel_grp(pcm_dev, ctx->nsamp, stride, ctx->mt, ctx->mel_grp, ctx->c.num_mel_bins, ctx->frames, ctx->mel32,
+                      ctx->chunk_max, batch, ctx->st);
+    launch_mel_finish_ex(ctx->mel32, ctx->chunk_max, ctx->mel_img, batch, ctx->c.num_mel_bins, ctx->frames, 1, ctx->st);
+    HIPCHK(hipEventRecord(ctx->ev[1], ctx->st));
+    HIPCHK(hipGetLastError());
+    ctx->have_mel = true;
+    return NH_OK;
+}
+
+extern "C" int nh_logmel_device(nh_ctx *ctx, const float *pcm_dev, const int32_t *n_samples, int64_t stride, int batch) {
+    if (!ctx || !pcm_dev || !n_samples) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_logmel_device: bad arguments") : NH_ERR_INVALID;
+    hipSetDevice(ctx->dev);
+    return run_logmel(ctx, pcm_dev, n_samples, stride, batch);
+}
+
+extern "C" int nh_logmel(nh_ctx *ctx, const float *pcm, const int32_t *n_samples, int64_t stride, int batch) {
+    if (!ctx || !pcm || !n_samples) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_logmel: bad arguments") : NH_ERR_INVALID;
+    hipSetDevice(ctx->dev);
+    if (batch < 1 || batch > ctx->B) return ctx->fail(NH_ERR_INVALID, "batch must be in [1, max_batch]");
+    for (int b = 0; b < batch; b++) {
+        if (n_samples[b] < 1 || n_samples[b] > NH_N_SAMPLES) return ctx->fail(NH_ERR_INVALID, "clip length must be in [1, 480000] samples");
+        HIPCHK(hipMemcpyAsync(ctx->pcm + (size_t)b * NH_N_SAMPLES, pcm + (size_t)b * stride, sizeof(float) * n_samples[b],
+                              hipMemcpyHostToDevice, ctx->st));
+    }
+    return run_logmel(ctx, ctx->pcm, n_samples, NH_N_SAMPLES, batch);
+}
+
+extern "C" int nh_get_mel(nh_ctx *ctx, int b, float *out) {
+    if (!ctx || !out) return NH_ERR_INVALID;
+    if (!ctx->have_mel || b < 0 || b >= ctx->cur_batch) return ctx->fail(NH_ERR_STATE, "nh_get_mel: no mel for that clip");
+    hipSetDevice(ctx->dev);
+    size_t per = (size_t)ctx->c.num_mel_bins * ctx->frames;
+    HIPCHK(hipMemcpyAsync(out, ctx->mel32 + per * b, per * 4, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    return NH_OK;
+}
+
+extern "C" int nh_set_mel(nh_ctx *ctx, const float *mel, int batch) {
+    if (!ctx || !mel) return NH_ERR_INVALID;
+    hipSetDevice(ctx->dev);
+    std::vector<int32_t> ns(batch > 0 ? batch : 1, NH_N_SAMPLES);
+    int rc = prepare_batch(ctx, ns.data(), batch);
+    if (rc) return rc;
+    size_t per = (size_t)ctx->c.num_mel_bins * NH_N_FRAMES;
+    HIPCHK(hipMemcpyAsync(ctx->mel32, mel, per * batch * 4, hipMemcpyHostToDevice, ctx->st));
+    launch_mel_finish_ex(ctx->mel32, ctx->chunk_max, ctx->mel_img, batch, ctx->c.num_mel_bins, ctx->frames, 0, ctx->st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    ctx->have_mel = true;
+    return NH_OK;
+}
+
+// ---- encoder ---------------------------------------------------------------------------------------------
+static void gemm_prof_begin(nh_ctx *ctx) {
+    if (!ctx->profile_gemm) return;
+    if (ctx->gemm_ev_used + 2 > ctx->gemm_ev.size()) {
+        for (int i = 0; i < 64; i++) { hipEvent_t e; hipEventCreate(&e); ctx->gemm_ev.push_back(e); }
+    }
+    hipEventRecord(ctx->gemm_ev[ctx->gemm_ev_used], ctx->st);
+}
+static void gemm_prof_end(nh_ctx *ctx, const GemmParams &p) {
+    if (!ctx->profile_gemm) return;
+    hipEventRecord(ctx->gemm_ev[ctx->gemm_ev_used + 1], ctx->st);
+    ctx->gemm_ev_used += 2;
+    ctx->gemm_flops_acc += 2.0 * (double)p.M * (double)p.N * (double)p.K;
+}
+
+static void gemm_plain(nh_ctx *ctx, const half_t *A, long lda, const LinW &W, int M, int N, int K, int epi, void *o0,
+                       void *o1, void *o2, int seg_n, long ldo, int vt_seg) {
+    GemmParams p{};
+    p.A = A; p.lda = lda; p.a_rpb = M; p.a_bstride = 0; p.W = W.w; p.bias = W.b; p.M = M; p.N = N; p.K = K; p.epi = epi;
+    p.out[0] = o0; p.out[1] = o1; p.out[2] = o2; p.seg_n = seg_n; p.ldo = ldo; p.o_rpb = M; p.o_bstride = 0; p.o_off = 0;
+    p.vt_seg = vt_seg; p.S = ctx->S; p.H = ctx->c.encoder_attention_heads; p.pos = nullptr;
+    gemm_prof_begin(ctx);
+    launch_gemm(p, ctx->st);
+    gemm_prof_end(ctx, p);
+}
+
+extern "C" int nh_encode(nh_ctx *ctx) {
+    if (!ctx) return NH_ERR_INVALID;
+    if (!ctx->have_mel) return ctx->fail(NH_ERR_STATE, "nh_encode: call nh_logmel first");
+    if (nh_missing_tensors(ctx) != 0) return ctx->fail(NH_ERR_STATE, "nh_encode: " + std::to_string(nh_missing_tensors(ctx)) + " tensors not loaded");
+    hipSetDevice(ctx->dev);
+    const int d = ctx->c.d_model, B = ctx->cur_batch, F = ctx->frames, S = ctx->S, H = ctx->c.encoder_attention_heads;
+    const int M = B * S;
+    ctx->gemm_ev_used = 0; ctx->gemm_flops_acc = 0.0;
+    HIPCHK(hipEventRecord(ctx->ev[2], ctx->st));
+    {   // conv1 + GELU: A rows overlap (lda = 128, K = 3 * 128) inside the zero-framed mel image
+        GemmParams p{};
+        p.A = ctx->mel_img; p.lda = NH_MELP; p.a_rpb = F; p.a_bstride = (long)(F + 2) * NH_MELP;
+        p.W = ctx->conv1.w; p.bias = ctx->conv1.b; p.M = B * F; p.N = d; p.K = 3 * NH_MELP; p.epi = EPI_GELU_F16;
+        p.out[0] = ctx->h1; p.seg_n = d; p.ldo = d; p.o_rpb = F; p.o_bstride = F + 2; p.o_off = 1; p.vt_seg = -1;
+        p.S = S; p.H = H;
+        gemm_prof_begin(ctx); launch_gemm(p, ctx->st); gemm_prof_end(ctx, p);
+    }
+    {   // conv2 (stride 2) + GELU + transpose + sinusoid positions -> f32 residual stream
+        GemmParams p{};
+        p.A = ctx->h1; p.lda = 2L * d; p.a_rpb = S; p.a_bstride = (long)(F + 2) * d;
+        p.W = ctx->conv2.w; p.bias = ctx->conv2.b; p.M = M; p.N = d; p.K = 3 * d; p.epi = EPI_CONV2_F32;
+        p.out[0] = ctx->x; p.seg_n = d; p.ldo = d; p.o_rpb = M; p.o_bstride = 0; p.o_off = 0; p.vt_seg = -1;
+        p.S = S; p.H = H; p.pos = ctx->enc_pos;
+        gemm_prof_begin(ctx); launch_gemm(p, ctx->st); gemm_prof_end(ctx, p);
+    }
+    for (auto &L : ctx->enc) {
+        launch_layernorm(ctx->x, L.ln1.w, L.ln1.b, ctx->xn, nullptr, M, d, ctx->st);
+        gemm_plain(ctx, ctx->xn, d, L.qkv, M, 3 * d, d, EPI_F16, ctx->q, ctx->k, ctx->vt, d, d, 2);
+        launch_enc_attention(ctx->q, ctx->k, d, ctx->vt, ctx->att, d, B, S, H, ctx->st);
+        gemm_plain(ctx, ctx->att, d, L.o, M, d, d, EPI_RESID_F32, ctx->x, nullptr, nullptr, d, d, -1);
+        launch_layernorm(ctx->x, L.ln2.w, L.ln2.b, ctx->xn, nullptr, M, d, ctx->st);
+        gemm_plain(ctx, ctx->xn, d, L.fc1, M, 4 * d, d, EPI_GELU_F16, ctx->hid, nullptr, nullptr, 4 * d, 4 * d, -1);
+        gemm_plain(ctx, ctx->hid, 4 * d, L.fc2, M, d, 4 * d, EPI_RESID_F32, ctx->x, nullptr, nullptr, d, d, -1);
+    }
+    launch_layernorm(ctx->x, ctx->ln_post.w, ctx->ln_post.b, ctx->xa16, ctx->xa32, M, d, ctx->st);
+    HIPCHK(hipEventRecord(ctx->ev[3], ctx->st));
+    // cross-attention K/V of every decoder layer (the flush = true work of MultiHeadAttention::forward)
+    for (auto &L : ctx->dec)
+        gemm_plain(ctx, ctx->xa16, d, L.ckv, M, 2 * d, d, EPI_F16, L.ck, L.cv, nullptr, d, d, -1);
+    HIPCHK(hipEventRecord(ctx->ev[4], ctx->st));
+    HIPCHK(hipGetLastError());
+    ctx->have_enc = true;
+    return NH_OK;
+}
+
+extern "C" int nh_encoder_output(nh_ctx *ctx, int b, float *out) {
+    if (!ctx || !out) return NH_ERR_INVALID;
+    if (!ctx->have_enc || b < 0 || b >= ctx->cur_batch) return ctx->fail(NH_ERR_STATE, "nh_encoder_output: no encoder output for that clip");
+    hipSetDevice(ctx->dev);
+    size_t per = (size_t)ctx->S * ctx->c.d_model;
+    HIPCHK(hipMemcpyAsync(out, ctx->xa32 + per * b, per * 4, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    return NH_OK;
+}
+
+// ---- decoder ---------------------------------------------------------------------------------------------
+static void skinny(nh_ctx *ctx, const half_t *x, long ldx, const LinW &W, int R, int N, int K, int epi, void *o0, void *o1,
+                   void *o2, long ldo, int t0, int ctxlen) {
+    SkinnyParams p{};
+    p.x = x; p.ldx = ldx; p.W = W.w; p.bias = W.b; p.R = R; p.N = N; p.K = K; p.epi = epi;
+    p.out[0] = o0; p.out[1] = o1; p.out[2] = o2; p.ldo = ldo; p.d = ctx->c.d_model; p.t0 = t0; p.Tn = 1; p.ctx = ctxlen;
+    launch_skinny(p, ctx->st);
+}
+
+// one decoder position for the whole batch: consumes tokens[b][pos], leaves LN(x) in dxn (fp16) / dy32 (f32)
+static void decoder_step(nh_ctx *ctx, int pos) {
+    const int d = ctx->c.d_model, B = ctx->cur_batch, H = ctx->c.decoder_attention_heads, C = ctx->c.max_target_positions;
+    launch_embed(ctx->ds.tokens, C, ctx->tok_emb, ctx->dec_pos, ctx->dx, B, 1, pos, d, ctx->st);
+    for (auto &L : ctx->dec) {
+        launch_layernorm(ctx->dx, L.ln1.w, L.ln1.b, ctx->dxn, nullptr, B, d, ctx->st);
+        skinny(ctx, ctx->dxn, d, L.qkv, B, 3 * d, d, SK_QKV, ctx->dq, L.sk, L.sv, d, pos, C);
+        launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos, ctx->st);
+        skinny(ctx, ctx->datt, d, L.o, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
+        launch_layernorm(ctx->dx, L.ln2.w, L.ln2.b, ctx->dxn, nullptr, B, d, ctx->st);
+        skinny(ctx, ctx->dxn, d, L.cq, B, d, d, SK_F16, ctx->dq, nullptr, nullptr, d, 0, C);
+        launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, -1, ctx->st);
+        skinny(ctx, ctx->datt, d, L.co, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
+        launch_layernorm(ctx->dx, L.ln3.w, L.ln3.b, ctx->dxn, nullptr, B, d, ctx->st);
+        skinny(ctx, ctx->dxn, d, L.fc1, B, 4 * d, d, SK_GELU_F16, ctx->dhid, nullptr, nullptr, 4 * d, 0, C);
+        skinny(ctx, ctx->dhid, 4 * d, L.fc2, B, d, 4 * d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
+    }
+    launch_layernorm(ctx->dx, ctx->dec_ln.w, ctx->dec_ln.b, ctx->dxn, ctx->dy32, B, d, ctx->st);
+}
+
+static void logits_from_dxn(nh_ctx *ctx, int R) {
+    LinW E; E.w = ctx->tok_emb; E.b = nullptr;  // tied embedding, no bias (final_linear)
+    skinny(ctx, ctx->dxn, ctx->c.d_model, E, R, ctx->c.vocab_size, ctx->c.d_model, SK_F32, ctx->logits, nullptr, nullptr,
+           ctx->VP, 0, 0);
+}
+
+extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *results, int max_new_tokens) {
+    if (!ctx || !out_tokens || !results) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_decode_greedy: bad arguments") : NH_ERR_INVALID;
+    if (!ctx->have_enc) return ctx->fail(NH_ERR_STATE, "nh_decode_greedy: call nh_encode first");
+    if (!ctx->have_tokens) return ctx->fail(NH_ERR_STATE, "nh_decode_greedy: call nh_set_tokens first");
+    hipSetDevice(ctx->dev);
+    const int B = ctx->cur_batch, C = ctx->c.max_target_positions, cap = C - 1, V = ctx->c.vocab_size;
+    // model.rs:285-289: prompt = [sot, lang?, task]
+    std::vector<int32_t> prompt;
+    prompt.push_back(ctx->tk.sot);
+    if (ctx->tk.lang >= 0) prompt.push_back(ctx->tk.lang);
+    prompt.push_back(ctx->tk.task);
+    const int P = (int)prompt.size();
+    std::vector<int32_t> toks((size_t)B * C, 0), nt(B, P);
+    for (int b = 0; b < B; b++) for (int i = 0; i < P; i++) toks[(size_t)b * C + i] = prompt[i];
+    HIPCHK(hipMemcpyAsync(ctx->ds.tokens, toks.data(), toks.size() * 4, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(ctx->ds.n_tokens, nt.data(), B * 4, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemsetAsync(ctx->ds.done, 0, B * 4, ctx->st));
+    HIPCHK(hipMemsetAsync(ctx->ds.have_last, 0, B * 4, ctx->st));
+    HIPCHK(hipMemsetAsync(ctx->ds.last_ts, 0, B * 4, ctx->st));
+    HIPCHK(hipMemsetAsync(ctx->ds.sum_logprob, 0, B * 8, ctx->st));
+    HIPCHK(hipMemsetAsync(ctx->ds.no_speech, 0, B * 8, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));  // toks/nt are stack-owned host buffers
+    HIPCHK(hipEventRecord(ctx->ev[5], ctx->st));
+    int steps = 0;
+    // position pos consumes tokens[pos]; from pos = P-1 on it also emits tokens[pos+1].  The length cap
+    // (model.rs:367) forces eot once pos + 2 >= cap, so pos never exceeds cap - 2.
+    for (int pos = 0; pos <= cap - 2; pos++) {
+        decoder_step(ctx, pos);
+        steps++;
+        if (pos == 0) {  // model.rs:293-305: logits at position 0 of the prompt pass -> no_speech_prob
+            logits_from_dxn(ctx, B);
+            launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 0, ctx->st);
+        }
+        if (pos >= P - 1) {
+            if (pos > 0) logits_from_dxn(ctx, B);
+            launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->st);
+            if (((pos - (P - 1)) & 15) == 15 || pos == cap - 2) {
+                HIPCHK(hipMemcpyAsync(ctx->h_done, ctx->ds.done, B * 4, hipMemcpyDeviceToHost, ctx->st));
+                HIPCHK(hipStreamSynchronize(ctx->st));
+                bool all = true;
+                for (int b = 0; b < B; b++) all = all && ctx->h_done[b] != 0;
+                if (all) break;
+            }
+        }
+    }
+    HIPCHK(hipEventRecord(ctx->ev[6], ctx->st));
+    std::vector<int32_t> done(B), hl(B);
+    std::vector<double> slp(B), nsp(B);
+    HIPCHK(hipMemcpyAsync(toks.data(), ctx->ds.tokens, toks.size() * 4, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(nt.data(), ctx->ds.n_tokens, B * 4, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(done.data(), ctx->ds.done, B * 4, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(slp.data(), ctx->ds.sum_logprob, B * 8, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(nsp.data(), ctx->ds.no_speech, B * 8, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    for (int b = 0; b < B; b++) {
+        int32_t *t = toks.data() + (size_t)b * C;
+        int n = nt[b];
+        nh_decode_result &r = results[b];
+        r.no_speech_prob = nsp[b];
+        r.no_speech_exit = (done[b] == 2);
+        if (done[b] == 2) { r.avg_logprob = 0.0; }  // model.rs:308-315
+        else {
+            r.avg_logprob = slp[b] / (double)n;  // model.rs:373 (prompt and eot count)
+            while (n >= 2 && t[n - 2] > ctx->tk.no_timestamps) { t[n - 2] = t[n - 1]; n--; }  // :375-381
+        }
+        r.n_tokens = n;
+        memcpy(out_tokens + (size_t)b * C, t, sizeof(int32_t) * C);
+        for (int i = n; i < C; i++) out_tokens[(size_t)b * C + i] = 0;
+    }
+    ctx->tm.decode_steps = steps;
+    return NH_OK;
+}
+
+extern "C" int nh_transcribe_batch(nh_ctx *ctx, const float *pcm_dev, const int32_t *n_samples, int64_t stride, int batch,
+                                   int32_t *out_tokens, nh_decode_result *results, int max_new_tokens) {
+    int rc = nh_logmel_device(ctx, pcm_dev, n_samples, stride, batch);
+    if (rc) return rc;
+    if ((rc = nh_encode(ctx))) return rc;
+    return nh_decode_greedy(ctx, out_tokens, results, max_new_tokens);
+}
+
+extern "C" int nh_reset(nh_ctx *ctx) {  // Type::reset_kv_cache (model.rs:485-490)
+    if (!ctx) return NH_ERR_INVALID;
+    ctx->have_enc = false;
+    return NH_OK;
+}
+
+extern "C" int nh_synchronize(nh_ctx *ctx) {
+    if (!ctx) return NH_ERR_INVALID;
+    hipSetDevice(ctx->dev);
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    return NH_OK;
+}
+
+extern "C" int nh_decoder_forward(nh_ctx *ctx, const int32_t *tokens, int T, float *hidden_out) {
+    if (!ctx || !tokens || !hidden_out) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_decoder_forward: bad arguments") : NH_ERR_INVALID;
+    if (!ctx->have_enc) return ctx->fail(NH_ERR_STATE, "nh_decoder_forward: call nh_encode first");
+    const int B = ctx->cur_batch, C = ctx->c.max_target_positions, d = ctx->c.d_model, V = ctx->c.vocab_size;
+    if (T < 1 || T > C) return ctx->fail(NH_ERR_INVALID, "nh_decoder_forward: T out of range");
+    hipSetDevice(ctx->dev);
+    std::vector<int32_t> toks((size_t)B * C, 0);
+    for (int b = 0; b < B; b++)
+        for (int i = 0; i < T; i++) {
+            int t = tokens[(size_t)b * T + i];
+            if (t < 0 || t >= V) return ctx->fail(NH_ERR_INVALID, "nh_decoder_forward: token id outside the vocabulary");
+            toks[(size_t)b * C + i] = t;
+        }
+    HIPCHK(hipMemcpyAsync(ctx->ds.tokens, toks.data(), toks.size() * 4, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    std::vector<float> row((size_t)B * d);
+    for (int pos = 0; pos < T; pos++) {
+        decoder_step(ctx, pos);
+        HIPCHK(hipMemcpyAsync(row.data(), ctx->dy32, row.size() * 4, hipMemcpyDeviceToHost, ctx->st));
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        for (int b = 0; b < B; b++) memcpy(hidden_out + ((size_t)b * T + pos) * d, row.data() + (size_t)b * d, sizeof(float) * d);
+    }
+    HIPCHK(hipGetLastError());
+    return NH_OK;
+}
+
+extern "C" int nh_final_linear(nh_ctx *ctx, const float *x, int rows, float *logits_out) {
+    if (!ctx || !x || !logits_out) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_final_linear: bad arguments") : NH_ERR_INVALID;
+    if (rows < 1 || rows > ctx->B) return ctx->fail(NH_ERR_INVALID, "nh_final_linear: rows must be in [1, max_batch]");
+    hipSetDevice(ctx->dev);
+    const int d = ctx->c.d_model, V = ctx->c.vocab_size;
+    std::vector<_Float16> h((size_t)rows * d);
+    for (size_t i = 0; i < h.size(); i++) h[i] = (_Float16)x[i];
+    HIPCHK(hipMemcpyAsync(ctx->dxn, h.data(), h.size() * 2, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    logits_from_dxn(ctx, rows);
+    for (int r = 0; r < rows; r++)
+        HIPCHK(hipMemcpyAsync(logits_out + (size_t)r * V, ctx->logits + (size_t)r * ctx->VP, sizeof(float) * V,
+                              hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipGetLastError());
+    return NH_OK;
+}
+
+extern "C" int nh_apply_rules(nh_ctx *ctx, const float *probs, const int32_t *tokens, int n_tokens, int last_timestamp,
+                              float *masked_out, int32_t *argmax_out) {
+    if (!ctx || !probs || !tokens || !masked_out || !argmax_out || n_tokens < 1)
+        return ctx ? ctx->fail(NH_ERR_INVALID, "nh_apply_rules: bad arguments") : NH_ERR_INVALID;
+    if (!ctx->have_tokens) return ctx->fail(NH_ERR_STATE, "nh_apply_rules: call nh_set_tokens first");
+    hipSetDevice(ctx->dev);
+    const int V = ctx->c.vocab_size;
+    float *d_in = ctx->logits, *d_out = ctx->logits + ctx->VP * (ctx->B > 1 ? 1 : 0);
+    float *tmp_out = nullptr;
+    if (ctx->B == 1) { if (hipMalloc(reinterpret_cast<void **>(&tmp_out), sizeof(float) * V) != hipSuccess) return ctx->fail(NH_ERR_NOMEM, "hipMalloc"); d_out = tmp_out; }
+    int32_t *d_tok = ctx->ds.tokens;
+    HIPCHK(hipMemcpyAsync(d_in, probs, sizeof(float) * V, hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(d_tok, tokens, sizeof(int32_t) * n_tokens, hipMemcpyHostToDevice, ctx->st));
+    launch_rules_only(d_in, d_out, ctx->ds.n_active, d_tok, n_tokens, last_timestamp, ctx->suppress, ctx->tk, V, ctx->st);
+    HIPCHK(hipMemcpyAsync(masked_out, d_out, sizeof(float) * V, hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipMemcpyAsync(argmax_out, ctx->ds.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    if (tmp_out) hipFree(tmp_out);
+    HIPCHK(hipGetLastError());
+    return NH_OK;
+}
+
+// ---- instrumentation -------------------------------------------------------------------------------------
+extern "C" int nh_set_profile_gemm(nh_ctx *ctx, int enable) {
+    if (!ctx) return NH_ERR_INVALID;
+    ctx->profile_gemm = enable != 0;
+    return NH_OK;
+}
+
+extern "C" int nh_get_timings(nh_ctx *ctx, nh_timings *out) {
+    if (!ctx || !out) return NH_ERR_INVALID;
+    hipSetDevice(ctx->dev);
+    HIPCHK(hipStreamSynchronize(ctx->st));
+    nh_timings t = ctx->tm;
+    hipEventElapsedTime(&t.mel_ms, ctx->ev[0], ctx->ev[1]);
+    hipEventElapsedTime(&t.encoder_ms, ctx->ev[2], ctx->ev[3]);
+    hipEventElapsedTime(&t.cross_kv_ms, ctx->ev[3], ctx->ev[4]);
+    hipEventElapsedTime(&t.decode_ms, ctx->ev[5], ctx->ev[6]);
+    t.gemm_ms = 0.f; t.gemm_launches = 0; t.gemm_flops = ctx->gemm_flops_acc;
+    for (size_t i = 0; i + 1 < ctx->gemm_ev_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->gemm_ev[i], ctx->gemm_ev[i + 1]) == hipSuccess) { t.gemm_ms += ms; t.gemm_launches++; }
+    }
+    *out = t;
+    return NH_OK;
+}

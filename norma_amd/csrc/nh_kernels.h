@@ -1,0 +1,115 @@
+// nh_kernels.h -- internal launch interface between the C-ABI layer (nh_api.hip) and the gfx950
+// kernels.  Not part of the public ABI (that is include/norma_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 half8;
+typedef __attribute__((ext_vector_type(4))) _Float16 half4;
+typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define NH_MELP 128   // mel channels padded to 128 in the fp16 conv1 input (K = 3*128)
+#define NH_SP 1536    // encoder sequence padded to a multiple of 64 for the V^T image
+#define NH_DH 64      // head dim of every Whisper size
+
+// ---- big MFMA GEMM: C[M][N] = A[M][K] . W[N][K]^T (+bias), fp16 in, fp32 accumulate ------------
+enum GemmEpi {
+    EPI_F16 = 0,        // fp16 out = acc + bias, up to 3 column segments with own destinations
+    EPI_GELU_F16 = 1,   // fp16 out = gelu_tanh(acc + bias)
+    EPI_RESID_F32 = 2,  // f32 x[m][n] += acc + bias
+    EPI_CONV2_F32 = 3,  // f32 x[m][n] = gelu_tanh(acc + bias) + pos[m % S][n]
+};
+
+struct GemmParams {
+    const half_t *A; long lda; int a_rpb; long a_bstride;  // row m at A + (m/a_rpb)*a_bstride + (m%a_rpb)*lda
+    const half_t *W;    // [N][K]
+    const float *bias;  // [N] or nullptr
+    int M, N, K;
+    int epi;
+    void *out[3]; int seg_n; long ldo;          // EPI_F16*: column segment s = n / seg_n goes to out[s]
+    int o_rpb; long o_bstride; long o_off;      // output row = (m/o_rpb)*o_bstride + (m%o_rpb) + o_off
+    int vt_seg;                                 // segment written as V^T [b][h][64][SP] (or -1)
+    int S, H;                                   // rows per clip / heads (V^T and conv2 epilogues)
+    const float *pos;                           // conv2: positional embedding [S][N]
+};
+void launch_gemm(const GemmParams &p, hipStream_t st);
+
+// ---- skinny GEMM for the decoder: y[R][N] = x[R][K] . W[N][K]^T, R <= 64 rows -------------------
+enum SkinnyEpi {
+    SK_F16 = 0,         // fp16 out (row stride ldo, per-row base offsets)
+    SK_GELU_F16 = 1,
+    SK_RESID_F32 = 2,   // f32 x[r][n] += acc + bias
+    SK_F32 = 3,         // f32 out = acc (+bias)  (logits)
+    SK_QKV = 4,         // self-attn fused q|k|v: q -> out[0] [R][d]; k,v -> caches at position t
+};
+struct SkinnyParams {
+    const half_t *x; long ldx;  // [R][K] fp16
+    const half_t *W; const float *bias;
+    int R, N, K;
+    int epi;
+    void *out[3]; long ldo;
+    // SK_QKV: row r = b*Tn + i  (Tn new positions per sequence); cache row = (b*ctx + t0 + i)
+    int d, t0, Tn, ctx;
+};
+void launch_skinny(const SkinnyParams &p, hipStream_t st);
+
+// ---- elementwise / normalisation -------------------------------------------------------------------
+// LayerNorm over rows of f32 x[M][d] -> fp16 y[M][d] (and optionally f32 y32[M][d])
+void launch_layernorm(const float *x, const float *w, const float *b, half_t *y, float *y32, int M, int d,
+                      hipStream_t st);
+// decoder input: x[(b*Tn+i)][:] = E[tokens[b*tok_stride + t0 + i]][:] + P[t0+i][:]
+void launch_embed(const int32_t *tokens, int tok_stride, const half_t *E, const half_t *P, float *x, int B,
+                  int Tn, int t0, int d, hipStream_t st);
+
+// ---- log-mel -------------------------------------------------------------------------------------------
+struct MelTables {      // device pointers, built once on the host with libm (bit-identical twiddles)
+    const float *hann;      // [400]
+    const float *dft_cos;   // [25][25]  cos(2pi*k*j/25) evaluated as candle's dft() does in f32
+    const float *dft_sin;   // [25][25]
+    const float *tw_cos;    // radix-2 twiddles for n = 50,100,200,400: offsets 0,25,75,175 (k < n/2)
+    const float *tw_sin;
+    const float *filters;   // [n_mel][201]
+};
+// pcm [B][stride] (device), n_samples[B] (device) -> mel32 f32 [B][n_mel][frames] (unnormalised
+// log10) and chunk_max[B] (order-preserving uint encoding of the per-clip max, atomicMax).
+// grp: [n_mel][2] first / last+1 group-of-4 index with a non-zero filter tap.
+void launch_logmel_grp(const float *pcm, const int32_t *n_samples, long stride, const MelTables &t,
+                       const int32_t *grp, int n_mel, int frames, float *mel32, unsigned *chunk_max, int B,
+                       hipStream_t st);
+// normalise=1: v = max(v, max-8)/4+1 in place; always writes the fp16 conv1 image [B][frames+2][128]
+void launch_mel_finish_ex(float *mel32, const unsigned *chunk_max, half_t *img, int B, int n_mel, int frames,
+                          int normalise, hipStream_t st);
+
+// ---- encoder attention ---------------------------------------------------------------------------------
+// q,k: fp16 [B*S][ld] (head h at column h*64); vt: fp16 [B][H][64][SP]; out: fp16 [B*S][ldo]
+void launch_enc_attention(const half_t *q, const half_t *k, long ld, const half_t *vt, half_t *out, long ldo,
+                          int B, int S, int H, hipStream_t st);
+
+// ---- decoder attention (one query row per (b, h, i)) -------------------------------------------------
+// q: fp16 [B*Tn][d]; kc,vc: fp16 [B][ctx][d]; keys visible to new row i: t0 + i + 1 (causal) or Tk (cross)
+void launch_dec_attention(const half_t *q, const half_t *kc, const half_t *vc, half_t *out, int B, int Tn,
+                          int H, int d, int ctx, int Tk, int causal_t0, hipStream_t st);
+
+// ---- logit processor: softmax + norma rules + argmax + bookkeeping -----------------------------------
+struct DecodeState {        // all device pointers
+    int32_t *tokens;        // [B][ctx]
+    int32_t *n_tokens;      // [B]
+    int32_t *done;          // [B] 0 running, 1 finished, 2 finished by no-speech early exit
+    int32_t *have_last;     // [B]
+    int32_t *last_ts;       // [B]
+    double *sum_logprob;    // [B]
+    double *no_speech;      // [B]
+    int32_t *n_active;      // [1] running sequences after the last step
+    const uint8_t *suppress;  // [V] 1 = suppressed (suppress_tokens U {no_timestamps})
+};
+struct RuleTokens { int sot, eot, lang, task, no_speech, no_timestamps, zero_sec, one_sec; };
+// mode 0: no-speech probe at prompt position 0; mode 1: generate a token from logits [B][V]
+void launch_logit_step(const float *logits, int V, DecodeState s, RuleTokens tk, int B, int ctx, int cap,
+                       int max_new, int prompt_len, int mode, hipStream_t st);
+// parity helper: apply rules to one already soft-maxed probability vector
+void launch_rules_only(const float *probs_in, float *masked_out, int32_t *argmax_out, const int32_t *tokens,
+                       int n_tokens, int last_ts, const uint8_t *suppress, RuleTokens tk, int V, hipStream_t st);

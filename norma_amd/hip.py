@@ -1,0 +1,272 @@
+"""ctypes binding of libnorma_hip.so (include/norma_hip.h) -- the only way Python reaches the HIP path.
+
+There is deliberately no CPU fallback here: if the shared library is missing or no MI355X is
+visible, construction fails loudly (the reference's `SelectedDevice::Cuda(n)` fails the same way
+when candle cannot open the device, `src/models/mod.rs:47-55`).
+"""
+import ctypes as C
+import os
+import re
+from typing import Iterable, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from .config import Config
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnorma_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "norma_hip.h")
+
+N_SAMPLES = 480000
+N_FRAMES = 3000
+NH_DTYPE_F32, NH_DTYPE_F16 = 0, 1
+
+
+class HipError(RuntimeError):
+    """A non-zero status from the C ABI (message = nh_last_error)."""
+
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"norma_hip status {code}: {msg}")
+        self.code = code
+
+
+class NhConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "num_mel_bins", "max_source_positions", "d_model", "encoder_attention_heads", "encoder_layers",
+        "vocab_size", "max_target_positions", "decoder_attention_heads", "decoder_layers")]
+
+
+class NhTokens(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("sot", "eot", "lang", "task", "no_speech", "no_timestamps", "zero_sec", "one_sec")]
+
+
+class NhDecodeResult(C.Structure):
+    _fields_ = [("n_tokens", C.c_int32), ("no_speech_exit", C.c_int32), ("avg_logprob", C.c_double),
+                ("no_speech_prob", C.c_double)]
+
+
+class NhTimings(C.Structure):
+    _fields_ = [("mel_ms", C.c_float), ("encoder_ms", C.c_float), ("cross_kv_ms", C.c_float),
+                ("decode_ms", C.c_float), ("decode_steps", C.c_int32), ("gemm_ms", C.c_float),
+                ("gemm_launches", C.c_int32), ("gemm_flops", C.c_double)]
+
+
+def declared_symbols() -> List[str]:
+    """Every function include/norma_hip.h declares (used by the CPU-side ABI test)."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    return sorted(set(re.findall(r"\b(nh_[a-z_0-9]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  norma_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)
+    L.nh_create.argtypes = [C.c_int, C.POINTER(NhConfig), C.c_int, C.POINTER(vp)]
+    L.nh_destroy.argtypes = [vp]
+    L.nh_destroy.restype = None
+    L.nh_last_error.argtypes = [vp]
+    L.nh_last_error.restype = C.c_char_p
+    L.nh_device_count.argtypes = []
+    L.nh_load_tensor.argtypes = [vp, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.c_int, vp]
+    L.nh_set_mel_filters.argtypes = [vp, fp, C.c_int]
+    L.nh_set_tokens.argtypes = [vp, C.POINTER(NhTokens), ip, C.c_int]
+    L.nh_missing_tensors.argtypes = [vp]
+    L.nh_logmel.argtypes = [vp, fp, ip, C.c_int64, C.c_int]
+    L.nh_logmel_device.argtypes = [vp, vp, ip, C.c_int64, C.c_int]
+    L.nh_encode.argtypes = [vp]
+    L.nh_decode_greedy.argtypes = [vp, ip, C.POINTER(NhDecodeResult), C.c_int]
+    L.nh_transcribe_batch.argtypes = [vp, vp, ip, C.c_int64, C.c_int, ip, C.POINTER(NhDecodeResult), C.c_int]
+    L.nh_reset.argtypes = [vp]
+    L.nh_synchronize.argtypes = [vp]
+    L.nh_get_mel.argtypes = [vp, C.c_int, fp]
+    L.nh_set_mel.argtypes = [vp, fp, C.c_int]
+    L.nh_encoder_output.argtypes = [vp, C.c_int, fp]
+    L.nh_decoder_forward.argtypes = [vp, ip, C.c_int, fp]
+    L.nh_final_linear.argtypes = [vp, fp, C.c_int, fp]
+    L.nh_apply_rules.argtypes = [vp, fp, ip, C.c_int, C.c_int, fp, ip]
+    L.nh_get_timings.argtypes = [vp, C.POINTER(NhTimings)]
+    L.nh_set_profile_gemm.argtypes = [vp, C.c_int]
+    _lib = L
+    return L
+
+
+def device_count() -> int:
+    return int(load_library().nh_device_count())
+
+
+def _fp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+class HipWhisper:
+    """One Whisper model resident on one MI355X (one `nh_ctx`).  Not thread-safe, like the
+    reference's `Model: Send` (one transcriber thread calls it, `src/lib.rs:462-464`)."""
+
+    def __init__(self, cfg: Config, device: int = 0, max_batch: int = 1):
+        self.L = load_library()
+        self.cfg = cfg
+        self.max_batch = max_batch
+        c = NhConfig(cfg.num_mel_bins, cfg.max_source_positions, cfg.d_model, cfg.encoder_attention_heads,
+                     cfg.encoder_layers, cfg.vocab_size, cfg.max_target_positions,
+                     cfg.decoder_attention_heads, cfg.decoder_layers)
+        h = C.c_void_p()
+        rc = self.L.nh_create(device, C.byref(c), max_batch, C.byref(h))
+        if rc != 0:
+            raise HipError(rc, self.L.nh_last_error(None).decode())
+        self._h = h
+        self.batch = 0
+
+    # -- lifetime ------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.nh_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc: int):
+        if rc != 0:
+            raise HipError(rc, self.L.nh_last_error(self._h).decode())
+
+    # -- model state ---------------------------------------------------------------------------
+    def load_tensor(self, name: str, arr: np.ndarray):
+        if arr.dtype == np.float16:
+            dt = NH_DTYPE_F16
+        else:
+            arr = np.ascontiguousarray(arr, dtype=np.float32)
+            dt = NH_DTYPE_F32
+        arr = np.ascontiguousarray(arr)
+        shape = (C.c_int64 * arr.ndim)(*arr.shape)
+        self._chk(self.L.nh_load_tensor(self._h, name.encode(), dt, shape, arr.ndim, arr.ctypes.data_as(C.c_void_p)))
+
+    def load_weights(self, weights: Iterable[Tuple[str, np.ndarray]]):
+        for name, arr in weights:
+            self.load_tensor(name, arr)
+        missing = self.L.nh_missing_tensors(self._h)
+        if missing:
+            raise HipError(3, f"{missing} tensors missing after load_weights")
+
+    def set_mel_filters(self, filters: np.ndarray):
+        f = np.ascontiguousarray(filters, dtype=np.float32)
+        self._chk(self.L.nh_set_mel_filters(self._h, _fp(f), f.shape[0]))
+
+    def set_tokens(self, tokens, lang: int, task: int, suppress: Optional[Sequence[int]] = None):
+        tk = NhTokens(tokens.sot, tokens.eot, lang, task, tokens.no_speech, tokens.no_timestamps,
+                      tokens.zero_sec, tokens.one_sec)
+        sup = np.asarray(self.cfg.suppress_tokens if suppress is None else suppress, dtype=np.int32)
+        self._chk(self.L.nh_set_tokens(self._h, C.byref(tk), _ip(sup), len(sup)))
+
+    # -- hot path ------------------------------------------------------------------------------
+    def logmel(self, clips: Sequence[np.ndarray]):
+        """clips: list of f32 PCM arrays (each <= 480000 samples)."""
+        B = len(clips)
+        ns = np.array([len(c) for c in clips], dtype=np.int32)
+        stride = int(max(ns.max(), 1))
+        buf = np.zeros((B, stride), dtype=np.float32)
+        for b, c in enumerate(clips):
+            buf[b, :len(c)] = c
+        self._chk(self.L.nh_logmel(self._h, _fp(buf), _ip(ns), stride, B))
+        self.batch = B
+
+    def get_mel(self, b: int, frames: int = N_FRAMES) -> np.ndarray:
+        out = np.zeros((self.cfg.num_mel_bins, frames), dtype=np.float32)
+        self._chk(self.L.nh_get_mel(self._h, b, _fp(out)))
+        return out
+
+    def set_mel(self, mel: np.ndarray):
+        mel = np.ascontiguousarray(mel, dtype=np.float32)
+        assert mel.ndim == 3 and mel.shape[1:] == (self.cfg.num_mel_bins, N_FRAMES)
+        self._chk(self.L.nh_set_mel(self._h, _fp(mel), mel.shape[0]))
+        self.batch = mel.shape[0]
+
+    def encode(self):
+        self._chk(self.L.nh_encode(self._h))
+
+    def encoder_output(self, b: int, S: int = 1500) -> np.ndarray:
+        out = np.zeros((S, self.cfg.d_model), dtype=np.float32)
+        self._chk(self.L.nh_encoder_output(self._h, b, _fp(out)))
+        return out
+
+    def _results(self, toks: np.ndarray, res) -> List[dict]:
+        out = []
+        for b in range(self.batch):
+            n = res[b].n_tokens
+            out.append(dict(tokens=toks[b, :n].tolist(), avg_logprob=res[b].avg_logprob,
+                            no_speech_prob=res[b].no_speech_prob, no_speech_exit=bool(res[b].no_speech_exit)))
+        return out
+
+    def decode_greedy(self, max_new_tokens: int = 0) -> List[dict]:
+        B = self.batch
+        toks = np.zeros((B, self.cfg.max_target_positions), dtype=np.int32)
+        res = (NhDecodeResult * B)()
+        self._chk(self.L.nh_decode_greedy(self._h, _ip(toks), res, max_new_tokens))
+        return self._results(toks, res)
+
+    def transcribe_batch_device(self, pcm_dev_ptr: int, n_samples: Sequence[int], stride: int,
+                                max_new_tokens: int = 0) -> List[dict]:
+        """pcm already resident in HBM (device pointer, f32 [batch][stride])."""
+        ns = np.asarray(n_samples, dtype=np.int32)
+        B = len(ns)
+        toks = np.zeros((B, self.cfg.max_target_positions), dtype=np.int32)
+        res = (NhDecodeResult * B)()
+        self._chk(self.L.nh_transcribe_batch(self._h, C.c_void_p(pcm_dev_ptr), _ip(ns), stride, B, _ip(toks), res,
+                                             max_new_tokens))
+        self.batch = B
+        return self._results(toks, res)
+
+    def reset(self):
+        self._chk(self.L.nh_reset(self._h))
+
+    def synchronize(self):
+        self._chk(self.L.nh_synchronize(self._h))
+
+    # -- fine-grained parity views ---------------------------------------------------------------
+    def decoder_forward(self, tokens: np.ndarray) -> np.ndarray:
+        tokens = np.ascontiguousarray(tokens, dtype=np.int32)
+        B, T = tokens.shape
+        assert B == self.batch
+        out = np.zeros((B, T, self.cfg.d_model), dtype=np.float32)
+        self._chk(self.L.nh_decoder_forward(self._h, _ip(tokens), T, _fp(out)))
+        return out
+
+    def final_linear(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.float32).reshape(-1, self.cfg.d_model)
+        out = np.zeros((x.shape[0], self.cfg.vocab_size), dtype=np.float32)
+        self._chk(self.L.nh_final_linear(self._h, _fp(x), x.shape[0], _fp(out)))
+        return out
+
+    def apply_rules(self, probs: np.ndarray, tokens: Sequence[int], last_timestamp: int):
+        p = np.ascontiguousarray(probs, dtype=np.float32)
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        out = np.zeros_like(p)
+        am = C.c_int32(0)
+        self._chk(self.L.nh_apply_rules(self._h, _fp(p), _ip(t), len(t), last_timestamp, _fp(out), C.byref(am)))
+        return out, int(am.value)
+
+    # -- instrumentation ---------------------------------------------------------------------------
+    def set_profile_gemm(self, enable: bool):
+        self._chk(self.L.nh_set_profile_gemm(self._h, int(enable)))
+
+    def timings(self) -> dict:
+        t = NhTimings()
+        self._chk(self.L.nh_get_timings(self._h, C.byref(t)))
+        return {n: getattr(t, n) for n, _ in NhTimings._fields_}

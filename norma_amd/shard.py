@@ -1,0 +1,65 @@
+"""Chunk-level data parallelism over the GPUs of one node.
+
+Independent 30-second chunks shard embarrassingly: weights are replicated, each rank owns a
+contiguous range of chunks, and there is NO data-path collective.  The only exchange is the optional
+gather of the (tiny) results, done with one all_gather over RCCL (backend "nccl" on ROCm) or gloo.
+The reference has no counterpart (it is single-stream, `src/lib.rs:462-464`).
+"""
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+
+def partition(n_chunks: int, world: int) -> List[Tuple[int, int]]:
+    """Contiguous (start, count) per rank; the first n % world ranks take one more
+    (20 chunks over 8 ranks -> 3,3,3,3,2,2,2,2)."""
+    q, r = divmod(n_chunks, world)
+    out, s = [], 0
+    for k in range(world):
+        c = q + (1 if k < r else 0)
+        out.append((s, c))
+        s += c
+    return out
+
+
+def pack_results(results: Sequence[dict], ctx_len: int, slots: int) -> np.ndarray:
+    """results -> int32 [slots][ctx_len + 6]: tokens | n | no_speech_exit | avg_logprob (2 x i32) |
+    no_speech_prob (2 x i32), doubles bit-cast so one integer tensor carries everything."""
+    buf = np.zeros((slots, ctx_len + 6), dtype=np.int32)
+    for i, r in enumerate(results):
+        t = r["tokens"]
+        buf[i, :len(t)] = t
+        buf[i, ctx_len] = len(t)
+        buf[i, ctx_len + 1] = int(r.get("no_speech_exit", False))
+        buf[i, ctx_len + 2:ctx_len + 6] = np.array([r["avg_logprob"], r["no_speech_prob"]], dtype=np.float64).view(np.int32)
+    return buf
+
+
+def unpack_results(buf: np.ndarray, ctx_len: int, count: int) -> List[dict]:
+    out = []
+    for i in range(count):
+        n = int(buf[i, ctx_len])
+        f = buf[i, ctx_len + 2:ctx_len + 6].copy().view(np.float64)
+        out.append(dict(tokens=buf[i, :n].tolist(), no_speech_exit=bool(buf[i, ctx_len + 1]),
+                        avg_logprob=float(f[0]), no_speech_prob=float(f[1])))
+    return out
+
+
+def gather_results(local: Sequence[dict], n_chunks: int, ctx_len: int, device=None) -> List[dict]:
+    """All ranks call this; every rank gets the results of all chunks in chunk order.
+    Requires an initialised torch.distributed process group (nccl -> pass the rank's cuda device)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(), dist.get_rank()
+    parts = partition(n_chunks, world)
+    slots = max(c for _, c in parts)
+    assert len(local) == parts[rank][1]
+    mine = torch.from_numpy(pack_results(local, ctx_len, slots))
+    if device is not None:
+        mine = mine.to(device)
+    bufs = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(bufs, mine)
+    out: List[dict] = []
+    for k, (_, c) in enumerate(parts):
+        out.extend(unpack_results(bufs[k].cpu().numpy(), ctx_len, c))
+    return out

@@ -8,6 +8,8 @@ import ctypes as C
 import os
 import subprocess
 
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")  # parked, not spinning, between parallel regions
+
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -34,6 +36,21 @@ def build(force: bool = False) -> str:
 
 
 _lib = None
+
+
+def default_threads() -> int:
+    env = os.environ.get("NORMA_ORACLE_THREADS")
+    if env:
+        return max(1, int(env))
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def set_num_threads(n: int):
+    lib().wo_set_num_threads(int(n))
 
 
 def lib():
@@ -64,6 +81,9 @@ def lib():
         L.wo_transcribe.argtypes = [C.c_void_p, fp, fp, C.POINTER(C.c_long), C.c_int, C.c_int, C.c_int,
                                     ip, C.c_int, ip, dp, dp]
         L.wo_num_threads.restype = C.c_int
+        L.wo_set_num_threads.argtypes = [C.c_int]
+        # never oversubscribe: GPU boxes expose every host core but grant a 16-core share
+        L.wo_set_num_threads(default_threads())
         _lib = L
     return _lib
 

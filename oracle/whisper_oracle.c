@@ -115,81 +115,91 @@ static void *xcalloc(size_t n, size_t sz) {
 /* ------------------------------------------------------------------------------------------ */
 /* GEMM: C[M][N] = A[M][K] * Bt[K][N] (+ bias[N]); every C element sums k = 0..K-1 in order.  */
 /* ------------------------------------------------------------------------------------------ */
-#define MR 4
+#define MR 6
 #define NR 16
 /* contractions use fused multiply-add explicitly (candle's CPU backend, the `gemm` crate, does the
  * same on x86); everything else is compiled with -ffp-contract=off like rustc would. */
 #define FMA8(a, b, c) ((v8)_mm256_fmadd_ps((__m256)(a), (__m256)(b), (__m256)(c)))
+static inline v8 bcast8(float x) { return (v8){x, x, x, x, x, x, x, x}; }
+
+/* rows [mlo,mhi) x columns [nlo,nhi): 6x16 register tiles over a packed 16-column panel of Bt */
 static void gemm_block(int mlo, int mhi, int nlo, int nhi, int K, const float *A, long lda,
-                       const float *Bt, long ldb, const float *bias, float *C, long ldc) {
-    for (int m0 = mlo; m0 < mhi; m0 += MR) {
-        int mr = mhi - m0 < MR ? mhi - m0 : MR;
-        int n0 = nlo;
-        for (; n0 + NR <= nhi; n0 += NR) {
-            v8 acc[MR][2];
-            for (int i = 0; i < MR; i++)
-                for (int j = 0; j < 2; j++) {
-                    if (bias) memcpy(&acc[i][j], bias + n0 + 8 * j, 32);
-                    else acc[i][j] = (v8){0, 0, 0, 0, 0, 0, 0, 0};
-                }
-            if (mr == MR) {
-                const float *a0 = A + (long)(m0 + 0) * lda, *a1 = A + (long)(m0 + 1) * lda;
-                const float *a2 = A + (long)(m0 + 2) * lda, *a3 = A + (long)(m0 + 3) * lda;
-                for (int k = 0; k < K; k++) {
-                    const float *bp = Bt + (long)k * ldb + n0;
-                    v8 b0, b1;
-                    memcpy(&b0, bp, 32); memcpy(&b1, bp + 8, 32);
-                    float x0 = a0[k], x1 = a1[k], x2 = a2[k], x3 = a3[k];
-                    v8 s0 = {x0, x0, x0, x0, x0, x0, x0, x0}, s1 = {x1, x1, x1, x1, x1, x1, x1, x1};
-                    v8 s2 = {x2, x2, x2, x2, x2, x2, x2, x2}, s3 = {x3, x3, x3, x3, x3, x3, x3, x3};
-                    acc[0][0] = FMA8(s0, b0, acc[0][0]); acc[0][1] = FMA8(s0, b1, acc[0][1]);
-                    acc[1][0] = FMA8(s1, b0, acc[1][0]); acc[1][1] = FMA8(s1, b1, acc[1][1]);
-                    acc[2][0] = FMA8(s2, b0, acc[2][0]); acc[2][1] = FMA8(s2, b1, acc[2][1]);
-                    acc[3][0] = FMA8(s3, b0, acc[3][0]); acc[3][1] = FMA8(s3, b1, acc[3][1]);
-                }
-            } else {
-                for (int k = 0; k < K; k++) {
-                    const float *bp = Bt + (long)k * ldb + n0;
-                    v8 b0, b1;
-                    memcpy(&b0, bp, 32); memcpy(&b1, bp + 8, 32);
-                    for (int i = 0; i < mr; i++) {
-                        float x = A[(long)(m0 + i) * lda + k];
-                        v8 s = {x, x, x, x, x, x, x, x};
-                        acc[i][0] = FMA8(s, b0, acc[i][0]); acc[i][1] = FMA8(s, b1, acc[i][1]);
-                    }
-                }
+                       const float *Bt, long ldb, const float *bias, float *C, long ldc, float *pack) {
+    int n0 = nlo;
+    for (; n0 + NR <= nhi; n0 += NR) {
+        for (int k = 0; k < K; k++) memcpy(pack + (long)k * NR, Bt + (long)k * ldb + n0, NR * sizeof(float));
+        v8 bz0 = {0, 0, 0, 0, 0, 0, 0, 0}, bz1 = bz0;
+        if (bias) { memcpy(&bz0, bias + n0, 32); memcpy(&bz1, bias + n0 + 8, 32); }
+        int m0 = mlo;
+        for (; m0 + MR <= mhi; m0 += MR) {
+            const float *a0 = A + (long)m0 * lda, *a1 = a0 + lda, *a2 = a1 + lda, *a3 = a2 + lda, *a4 = a3 + lda,
+                        *a5 = a4 + lda;
+            v8 c00 = bz0, c01 = bz1, c10 = bz0, c11 = bz1, c20 = bz0, c21 = bz1, c30 = bz0, c31 = bz1, c40 = bz0,
+               c41 = bz1, c50 = bz0, c51 = bz1;
+            const float *bp = pack;
+            for (int k = 0; k < K; k++, bp += NR) {
+                v8 b0, b1;
+                memcpy(&b0, bp, 32); memcpy(&b1, bp + 8, 32);
+                v8 s;
+                s = bcast8(a0[k]); c00 = FMA8(s, b0, c00); c01 = FMA8(s, b1, c01);
+                s = bcast8(a1[k]); c10 = FMA8(s, b0, c10); c11 = FMA8(s, b1, c11);
+                s = bcast8(a2[k]); c20 = FMA8(s, b0, c20); c21 = FMA8(s, b1, c21);
+                s = bcast8(a3[k]); c30 = FMA8(s, b0, c30); c31 = FMA8(s, b1, c31);
+                s = bcast8(a4[k]); c40 = FMA8(s, b0, c40); c41 = FMA8(s, b1, c41);
+                s = bcast8(a5[k]); c50 = FMA8(s, b0, c50); c51 = FMA8(s, b1, c51);
             }
-            for (int i = 0; i < mr; i++) {
-                memcpy(C + (long)(m0 + i) * ldc + n0, &acc[i][0], 32);
-                memcpy(C + (long)(m0 + i) * ldc + n0 + 8, &acc[i][1], 32);
-            }
+            float *c = C + (long)m0 * ldc + n0;
+            memcpy(c, &c00, 32); memcpy(c + 8, &c01, 32); c += ldc;
+            memcpy(c, &c10, 32); memcpy(c + 8, &c11, 32); c += ldc;
+            memcpy(c, &c20, 32); memcpy(c + 8, &c21, 32); c += ldc;
+            memcpy(c, &c30, 32); memcpy(c + 8, &c31, 32); c += ldc;
+            memcpy(c, &c40, 32); memcpy(c + 8, &c41, 32); c += ldc;
+            memcpy(c, &c50, 32); memcpy(c + 8, &c51, 32);
         }
-        for (; n0 < nhi; n0++) { /* column tail, same k order (fused multiply-add like above) */
-            for (int i = 0; i < mr; i++) {
-                float acc = bias ? bias[n0] : 0.f;
-                for (int k = 0; k < K; k++)
-                    acc = __builtin_fmaf(A[(long)(m0 + i) * lda + k], Bt[(long)k * ldb + n0], acc);
-                C[(long)(m0 + i) * ldc + n0] = acc;
+        for (; m0 < mhi; m0++) { /* row tail, same k order */
+            const float *a0 = A + (long)m0 * lda;
+            v8 c0 = bz0, c1 = bz1;
+            const float *bp = pack;
+            for (int k = 0; k < K; k++, bp += NR) {
+                v8 b0, b1;
+                memcpy(&b0, bp, 32); memcpy(&b1, bp + 8, 32);
+                v8 s = bcast8(a0[k]);
+                c0 = FMA8(s, b0, c0); c1 = FMA8(s, b1, c1);
             }
+            memcpy(C + (long)m0 * ldc + n0, &c0, 32); memcpy(C + (long)m0 * ldc + n0 + 8, &c1, 32);
+        }
+    }
+    for (; n0 < nhi; n0++) { /* column tail, same k order and the same fused multiply-add */
+        for (int m = mlo; m < mhi; m++) {
+            float acc = bias ? bias[n0] : 0.f;
+            for (int k = 0; k < K; k++) acc = __builtin_fmaf(A[(long)m * lda + k], Bt[(long)k * ldb + n0], acc);
+            C[(long)m * ldc + n0] = acc;
         }
     }
 }
 
 static void gemm(int M, int N, int K, const float *A, long lda, const float *Bt, long ldb,
                  const float *bias, float *C, long ldc, int parallel) {
-    const int MB = 64, NB = 256;
+    const int MB = 192, NB = 64;
     int mblocks = (M + MB - 1) / MB, nblocks = (N + NB - 1) / NB;
     if (!parallel || (long)M * N * K < 200000) {
-        gemm_block(0, M, 0, N, K, A, lda, Bt, ldb, bias, C, ldc);
+        float *pack = (float *)xcalloc((size_t)K * NR, sizeof(float));
+        gemm_block(0, M, 0, N, K, A, lda, Bt, ldb, bias, C, ldc, pack);
+        free(pack);
         return;
     }
-#pragma omp parallel for collapse(2) schedule(dynamic, 1)
-    for (int mb = 0; mb < mblocks; mb++)
-        for (int nb = 0; nb < nblocks; nb++) {
-            int mlo = mb * MB, mhi = mlo + MB < M ? mlo + MB : M;
-            int nlo = nb * NB, nhi = nlo + NB < N ? nlo + NB : N;
-            gemm_block(mlo, mhi, nlo, nhi, K, A, lda, Bt, ldb, bias, C, ldc);
-        }
+#pragma omp parallel
+    {
+        float *pack = (float *)xcalloc((size_t)K * NR, sizeof(float));
+#pragma omp for collapse(2) schedule(dynamic, 1)
+        for (int mb = 0; mb < mblocks; mb++)
+            for (int nb = 0; nb < nblocks; nb++) {
+                int mlo = mb * MB, mhi = mlo + MB < M ? mlo + MB : M;
+                int nlo = nb * NB, nhi = nlo + NB < N ? nlo + NB : N;
+                gemm_block(mlo, mhi, nlo, nhi, K, A, lda, Bt, ldb, bias, C, ldc, pack);
+            }
+        free(pack);
+    }
 }
 
 static void linear(const lin_t *l, const float *x, int M, float *y) {
@@ -915,6 +925,14 @@ int wo_transcribe(wo_model *m, const float *filters, float *buf, long *buf_len, 
     if (final_chunk) { wo_reset_kv_cache(m); } /* :153-156 (lang.clear() is a no-op for ConstLang) */
     free(tokens);
     return n_out;
+}
+
+void wo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 int wo_num_threads(void) {
