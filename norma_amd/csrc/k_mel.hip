@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void logmel_kernel(MelArgs a) {
             sum += pf[k] * f[k] + pf[k + 1] * f[k + 1] + pf[k + 2] * f[k + 2] + pf[k + 3] * f[k + 3];
         }
         sum += pf[200] * f[200];  // remainder term k = 200
-        float v = log10f(sum > 1e-10f ? sum : 1e-10f);
+        float v = sum > 1e-10f ? log10f(sum) : -10.0f;  // log10f(1e-10f) is exactly -10 in the reference's libm
         if (live) {
             a.mel32[((long)b * a.n_mel + m) * a.frames + frame] = v;
             lmax = fmaxf(lmax, v);

@@ -750,18 +750,21 @@ extern "C" int nh_decoder_forward(nh_ctx *ctx, const int32_t *tokens, int T, flo
 
 extern "C" int nh_final_linear(nh_ctx *ctx, const float *x, int rows, float *logits_out) {
     if (!ctx || !x || !logits_out) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_final_linear: bad arguments") : NH_ERR_INVALID;
-    if (rows < 1 || rows > ctx->B) return ctx->fail(NH_ERR_INVALID, "nh_final_linear: rows must be in [1, max_batch]");
+    if (rows < 1) return ctx->fail(NH_ERR_INVALID, "nh_final_linear: rows must be >= 1");
     hipSetDevice(ctx->dev);
     const int d = ctx->c.d_model, V = ctx->c.vocab_size;
-    std::vector<_Float16> h((size_t)rows * d);
-    for (size_t i = 0; i < h.size(); i++) h[i] = (_Float16)x[i];
-    HIPCHK(hipMemcpyAsync(ctx->dxn, h.data(), h.size() * 2, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
-    logits_from_dxn(ctx, rows);
-    for (int r = 0; r < rows; r++)
-        HIPCHK(hipMemcpyAsync(logits_out + (size_t)r * V, ctx->logits + (size_t)r * ctx->VP, sizeof(float) * V,
-                              hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
+    std::vector<_Float16> h((size_t)ctx->B * d);
+    for (int r0 = 0; r0 < rows; r0 += ctx->B) {  // the workspace holds max_batch rows at a time
+        const int nr = rows - r0 < ctx->B ? rows - r0 : ctx->B;
+        for (size_t i = 0; i < (size_t)nr * d; i++) h[i] = (_Float16)x[(size_t)r0 * d + i];
+        HIPCHK(hipMemcpyAsync(ctx->dxn, h.data(), (size_t)nr * d * 2, hipMemcpyHostToDevice, ctx->st));
+        HIPCHK(hipStreamSynchronize(ctx->st));
+        logits_from_dxn(ctx, nr);
+        for (int r = 0; r < nr; r++)
+            HIPCHK(hipMemcpyAsync(logits_out + (size_t)(r0 + r) * V, ctx->logits + (size_t)r * ctx->VP, sizeof(float) * V,
+                                  hipMemcpyDeviceToHost, ctx->st));
+        HIPCHK(hipStreamSynchronize(ctx->st));
+    }
     HIPCHK(hipGetLastError());
     return NH_OK;
 }

@@ -420,11 +420,19 @@ void wo_free(wo_model *m) {
     free(m);
 }
 
-/* store W[n_out][n_in] transposed */
+/* store W[n_out][n_in] transposed (blocked, so both sides stay cache friendly) */
+static void transpose_into(float *dst, const float *src, long rows, long cols) { /* dst[c][r] = src[r][c] */
+#pragma omp parallel for collapse(2) schedule(static)
+    for (long r0 = 0; r0 < rows; r0 += 64)
+        for (long c0 = 0; c0 < cols; c0 += 64) {
+            long r1 = r0 + 64 < rows ? r0 + 64 : rows, c1 = c0 + 64 < cols ? c0 + 64 : cols;
+            for (long r = r0; r < r1; r++)
+                for (long c = c0; c < c1; c++) dst[c * rows + r] = src[r * cols + c];
+        }
+}
 static int set_lin_w(lin_t *l, const float *w, long n) {
     if (n != (long)l->n_out * l->n_in) return -2;
-    for (int o = 0; o < l->n_out; o++)
-        for (int i = 0; i < l->n_in; i++) l->wt[(long)i * l->n_out + o] = w[(long)o * l->n_in + i];
+    transpose_into(l->wt, w, l->n_out, l->n_in);
     return 0;
 }
 static int set_vec(float *dst, long want, const float *src, long n) {
@@ -481,8 +489,7 @@ int wo_set_tensor(wo_model *m, const char *name, const float *data, long n) {
     if (!strcmp(name, "model.decoder.embed_tokens.weight")) {
         if (n != (long)m->c.n_vocab * d) return -2;
         memcpy(m->tok_emb, data, sizeof(float) * (size_t)n);
-        for (long v = 0; v < m->c.n_vocab; v++)
-            for (int i = 0; i < d; i++) m->tok_emb_t[(long)i * m->c.n_vocab + v] = data[v * d + i];
+        transpose_into(m->tok_emb_t, data, m->c.n_vocab, d);
         return 0;
     }
     if (!strcmp(name, "model.decoder.embed_positions.weight"))
