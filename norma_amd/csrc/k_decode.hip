@@ -19,68 +19,17 @@ __device__ __forceinline__ float gelu_tanh_d(float v) {
 }
 
 // ---------------------------------------------------------------------------------------------------
-// skinny GEMM: y[R][N] = x[R][K] . W[N][K]^T, R <= 64.  One workgroup = 16 output features; its 4
-// waves split K; weights are the MFMA A operand (each lane streams 16 B of one weight row per step,
-// 4 lanes cover a 64 B run), activations (L2-resident) the B operand; fp32 partials meet in LDS.
+// skinny GEMM: y[R][N] = x[R][K] . W[N][K]^T, R <= 64.  Weights are the MFMA A operand (16 rows per
+// tile; each lane streams 16 B of one weight row per k-step, 4 lanes cover a 64 B run), activations
+// (L2-resident) the B operand.  Two shapes of the same kernel:
+//   KSPLIT = 4 | 8 : one 16-row tile per workgroup, its KSPLIT waves split K, fp32 partials meet in
+//                    LDS (small N: many waves in flight instead of few long ones);
+//   KSPLIT = 1     : every wave owns NT 16-row tiles over the full K, no LDS (the 51866-row logits).
+// Up to 8 k-steps of loads are in flight per wave before the first MFMA of a group.
 // ---------------------------------------------------------------------------------------------------
-template <int NCB>
-__global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyParams p) {
-    __shared__ f32x4 red[4][NCB][64];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    int wrow = n0 + fr; if (wrow >= p.N) wrow = p.N - 1;
-    const int kslice = p.K >> 2, kbeg = w * kslice;
-    const half_t *wp = p.W + (long)wrow * p.K + kbeg + 8 * fq;
-    const half_t *xp[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; cb++) {
-        int r = 16 * cb + fr; if (r >= p.R) r = p.R - 1;
-        xp[cb] = p.x + (long)r * p.ldx + kbeg + 8 * fq;
-    }
-    f32x4 acc[NCB];
-#pragma unroll
-    for (int cb = 0; cb < NCB; cb++) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int steps = kslice >> 5;
-    int s = 0;
-    for (; s + 4 <= steps; s += 4) {  // 4 weight loads in flight per lane
-        half8 a0 = *reinterpret_cast<const half8 *>(wp + 32 * (s + 0));
-        half8 a1 = *reinterpret_cast<const half8 *>(wp + 32 * (s + 1));
-        half8 a2 = *reinterpret_cast<const half8 *>(wp + 32 * (s + 2));
-        half8 a3 = *reinterpret_cast<const half8 *>(wp + 32 * (s + 3));
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++) {
-            half8 b0 = *reinterpret_cast<const half8 *>(xp[cb] + 32 * (s + 0));
-            half8 b1 = *reinterpret_cast<const half8 *>(xp[cb] + 32 * (s + 1));
-            half8 b2 = *reinterpret_cast<const half8 *>(xp[cb] + 32 * (s + 2));
-            half8 b3 = *reinterpret_cast<const half8 *>(xp[cb] + 32 * (s + 3));
-            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[cb], 0, 0, 0);
-            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, b1, acc[cb], 0, 0, 0);
-            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a2, b2, acc[cb], 0, 0, 0);
-            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a3, b3, acc[cb], 0, 0, 0);
-        }
-    }
-    for (; s < steps; s++) {
-        half8 a0 = *reinterpret_cast<const half8 *>(wp + 32 * s);
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++) {
-            half8 b0 = *reinterpret_cast<const half8 *>(xp[cb] + 32 * s);
-            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, b0, acc[cb], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int cb = 0; cb < NCB; cb++) red[w][cb][lane] = acc[cb];
-    __syncthreads();
-    // thread t owns row r = t / 4 and the 4 consecutive features n0 + 4 (t % 4) + i:
-    // D[n = 4 fq + i][r = fr] lives in lane 16 fq + fr of column block r / 16
-    const int r = tid >> 2, nq = tid & 3;
-    if (r >= 16 * NCB || r >= p.R) return;
-    const int src_lane = 16 * nq + (r & 15), cb = r >> 4;
-    f32x4 v = red[0][cb][src_lane];
-    v += red[1][cb][src_lane];
-    v += red[2][cb][src_lane];
-    v += red[3][cb][src_lane];
-    const int n = n0 + 4 * nq;
+#define SK_U 10
+
+__device__ __forceinline__ void skinny_store(const SkinnyParams &p, f32x4 v, int r, int n) {
     if (n >= p.N) return;
     if (p.bias) {
         if (n + 3 < p.N) v += *reinterpret_cast<const f32x4 *>(p.bias + n);
@@ -106,20 +55,154 @@ __global__ __launch_bounds__(256) void skinny_gemm_kernel(SkinnyParams p) {
         const int b = r / p.Tn, i = r - b * p.Tn;
         half_t *dst;
         if (sg == 0) dst = reinterpret_cast<half_t *>(p.out[0]) + (long)r * p.d + nl;
-        else dst = reinterpret_cast<half_t *>(sg == 1 ? p.out[1] : p.out[2]) + ((long)b * p.ctx + p.t0 + i) * p.d + nl;
+        else {
+            const int t0 = p.pos_ptr ? *p.pos_ptr : p.t0;
+            dst = reinterpret_cast<half_t *>(sg == 1 ? p.out[1] : p.out[2]) + ((long)b * p.ctx + t0 + i) * p.d + nl;
+        }
         *reinterpret_cast<half4 *>(dst) = hv;
         return;
     }
     *reinterpret_cast<half4 *>(reinterpret_cast<half_t *>(p.out[0]) + (long)r * p.ldo + n) = hv;
 }
 
-void launch_skinny(const SkinnyParams &p, hipStream_t st) {
-    dim3 grid((p.N + 15) / 16), block(256);
+// HBM feeds a CU at ~24 GB/s, so a weight matrix has to be spread over ALL 256 CUs to stream at chip
+// rate: small-N layers split K across workgroups too (gridDim.y = KS).  Each workgroup publishes its
+// fp32 partial tile with write-through (sc1) stores and takes a ticket; the last one to arrive adds
+// the KS partials in slice order (deterministic, independent of arrival order) and runs the epilogue.
+template <int NCB, int KSPLIT, int NT>
+__global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_kernel(SkinnyParams p, float *slabs,
+                                                                                      unsigned *tickets) {
+    constexpr int NW = KSPLIT == 1 ? 2 : KSPLIT;  // waves per workgroup
+    __shared__ f32x4 red[KSPLIT == 1 ? 1 : KSPLIT][NCB][64];
+    __shared__ int sh_last;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int KS = gridDim.y, ks = blockIdx.y;
+    // tile base row of this wave
+    const int n0 = KSPLIT == 1 ? (blockIdx.x * NW + w) * 16 * NT : blockIdx.x * 16;
+    const int kslice = p.K / (KSPLIT * KS), kbeg = KSPLIT == 1 ? 0 : (ks * KSPLIT + w) * kslice;
+    const half_t *wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        int wrow = n0 + 16 * t + fr; if (wrow >= p.N) wrow = p.N - 1;
+        wp[t] = p.W + (long)wrow * p.K + kbeg + 8 * fq;
+    }
+    const half_t *xp[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        int r = 16 * cb + fr; if (r >= p.R) r = p.R - 1;
+        xp[cb] = p.x + (long)r * p.ldx + kbeg + 8 * fq;
+    }
+    f32x4 acc[NT][NCB];
+#pragma unroll
+    for (int t = 0; t < NT; t++)
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc[t][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int steps = kslice >> 5;
+    for (int s0 = 0; s0 < steps; s0 += SK_U) {
+        half8 a[NT][SK_U], b[NCB][SK_U];
+#pragma unroll
+        for (int u = 0; u < SK_U; u++) {
+            if (s0 + u < steps) {  // wave-uniform
+#pragma unroll
+                for (int t = 0; t < NT; t++) a[t][u] = *reinterpret_cast<const half8 *>(wp[t] + 32 * (s0 + u));
+#pragma unroll
+                for (int cb = 0; cb < NCB; cb++) b[cb][u] = *reinterpret_cast<const half8 *>(xp[cb] + 32 * (s0 + u));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SK_U; u++) {
+            if (s0 + u < steps) {
+#pragma unroll
+                for (int t = 0; t < NT; t++)
+#pragma unroll
+                    for (int cb = 0; cb < NCB; cb++)
+                        acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][u], b[cb][u], acc[t][cb], 0, 0, 0);
+            }
+        }
+    }
+    if (KSPLIT == 1) {
+        // D[n = 4 fq + i][r = 16 cb + fr]: each lane already holds 4 consecutive features of one row
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) {
+                int r = 16 * cb + fr;
+                if (r < p.R) skinny_store(p, acc[t][cb], r, n0 + 16 * t + 4 * fq);
+            }
+        return;
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) red[w][cb][lane] = acc[0][cb];
+    __syncthreads();
+    // thread t owns row r = t / 4 and the 4 consecutive features n0 + 4 (t % 4) + i:
+    // D[n = 4 fq + i][r = fr] lives in lane 16 fq + fr of column block r / 16
+    const int r = tid >> 2, nq = tid & 3;
+    const bool owner = (tid < 64 * NCB) && (r < p.R);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (owner) {
+        const int src_lane = 16 * nq + (r & 15), cb = r >> 4;
+        v = red[0][cb][src_lane];
+#pragma unroll
+        for (int ww = 1; ww < KSPLIT; ww++) v += red[ww][cb][src_lane];
+    }
+    if (KS == 1) {
+        if (owner) skinny_store(p, v, r, n0 + 4 * nq);
+        return;
+    }
+    // cross-workgroup split-K: slab[tile][ks][r][nq] (f32x4 as 4 write-through dwords)
+    float *slab = slabs + ((long)blockIdx.x * KS) * 64 * 16;
+    if (owner) {
+        float *dst = slab + ((long)ks * 64 + r) * 16 + 4 * nq;
+#pragma unroll
+        for (int i = 0; i < 4; i++) __hip_atomic_store(dst + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
+    __syncthreads();
+    if (tid == 0) {
+        unsigned t = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = (t == (unsigned)KS - 1);
+        if (sh_last) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (!sh_last || !owner) return;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < KS; q++) {  // slice order, not arrival order; sc1 loads bypass this CU's L1
+        const float *src = slab + ((long)q * 64 + r) * 16 + 4 * nq;
+#pragma unroll
+        for (int i = 0; i < 4; i++) sum[i] += __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    skinny_store(p, sum, r, n0 + 4 * nq);
+}
+
+template <int NCB>
+static void launch_skinny_ncb(const SkinnyParams &p, float *slabs, unsigned *tickets, hipStream_t st) {
+    const int tiles = (p.N + 15) / 16;
+    if (tiles >= 2048) {  // the tied-embedding logits: plenty of tiles, stream full rows
+        constexpr int NT = 2;
+        int waves = (tiles + NT - 1) / NT;
+        hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 1, NT>), dim3((waves + 1) / 2), dim3(128), 0, st, p, slabs, tickets);
+        return;
+    }
+    // waves per workgroup (in-block split) x KS workgroups per tile: aim at >= 2 workgroups per CU-ish
+    // while every wave keeps a whole number of 32-deep k-steps
+    int ks = 1;
+    auto fits = [&](int nw, int k) { return p.K % (nw * k * 32) == 0; };
+    int nw = fits(4, 1) ? 4 : (fits(2, 1) ? 2 : 0);
+    if (slabs && tiles <= SKINNY_MAX_TILES) {
+        while (tiles * ks < 320 && ks < 8 && nw && fits(nw, ks * 2)) ks *= 2;
+        if (tiles * ks < 320 && nw == 4 && fits(2, ks * 2) && ks < 8) { nw = 2; ks *= 2; }
+    }
+    if (nw == 4) hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 4, 1>), dim3(tiles, ks), dim3(256), 0, st, p, slabs, tickets);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 2, 1>), dim3(tiles, ks), dim3(128), 0, st, p, slabs, tickets);
+}
+
+void launch_skinny(const SkinnyParams &p, float *slabs, unsigned *tickets, hipStream_t st) {
     int ncb = (p.R + 15) / 16;
-    if (ncb <= 1) hipLaunchKernelGGL(skinny_gemm_kernel<1>, grid, block, 0, st, p);
-    else if (ncb == 2) hipLaunchKernelGGL(skinny_gemm_kernel<2>, grid, block, 0, st, p);
-    else if (ncb == 3) hipLaunchKernelGGL(skinny_gemm_kernel<3>, grid, block, 0, st, p);
-    else hipLaunchKernelGGL(skinny_gemm_kernel<4>, grid, block, 0, st, p);
+    if (ncb <= 1) launch_skinny_ncb<1>(p, slabs, tickets, st);
+    else if (ncb == 2) launch_skinny_ncb<2>(p, slabs, tickets, st);
+    else if (ncb == 3) launch_skinny_ncb<3>(p, slabs, tickets, st);
+    else launch_skinny_ncb<4>(p, slabs, tickets, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -140,7 +223,8 @@ __device__ __forceinline__ void merge_part(AttnPart &a, float mo, float lo, cons
 
 __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict__ q, const half_t *__restrict__ kc,
                                                        const half_t *__restrict__ vc, half_t *__restrict__ out,
-                                                       int d, int ctx, int Tk) {
+                                                       int d, int ctx, int Tk, const int32_t *__restrict__ pos_ptr) {
+    if (pos_ptr) Tk = *pos_ptr + 1;
     __shared__ float part[4][8][10];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int slot = lane >> 3, pp = lane & 7;
@@ -219,9 +303,9 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict_
 }
 
 void launch_dec_attention(const half_t *q, const half_t *kc, const half_t *vc, half_t *out, int B, int Tn,
-                          int H, int d, int ctx, int Tk, int causal_t0, hipStream_t st) {
-    (void)Tn; (void)causal_t0;  // one new position per sequence; its visible keys are exactly Tk
-    hipLaunchKernelGGL(dec_attn_kernel, dim3(H, B), dim3(256), 0, st, q, kc, vc, out, d, ctx, Tk);
+                          int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st) {
+    (void)Tn;  // one new position per sequence; its visible keys are exactly Tk (or *pos_ptr + 1)
+    hipLaunchKernelGGL(dec_attn_kernel, dim3(H, B), dim3(256), 0, st, q, kc, vc, out, d, ctx, Tk, pos_ptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -321,54 +405,175 @@ __device__ __forceinline__ void rules_argmax(ProbFn probs, int V, const int32_t 
     rule_out = rule; next_out = oi;
 }
 
-__global__ __launch_bounds__(1024) void logit_step_kernel(const float *__restrict__ logits, int V, int ldl,
-                                                          DecodeState s, RuleTokens tk, int ctx, int cap,
-                                                          int max_new, int prompt_len, int mode) {
-    __shared__ BlockRed sm;
-    const int b = blockIdx.x;
+// ---- the fused decode-step version: ONE sweep over the logits, LSPLIT workgroups per sequence -----------
+// softmax is monotonic, so the arg max over an allowed set can be taken on the logits; which set is
+// allowed is known before the sweep except for the "last token is text" case, where both candidates
+// (best timestamp after last_ts, best allowed text token) are tracked and the choice
+// sum_ts >= max_text is made by the last workgroup to arrive.  (Two DISTINCT logits whose f32
+// probabilities round to the same value would tie in the reference and resolve to the higher index;
+// here the larger logit wins.  That needs a relative gap < 6e-8 and is far below the fp16 noise floor.)
+#define LSPLIT 8
+
+__device__ __forceinline__ void merge_ms(float &m, float &s, float &ts, float m2, float s2, float ts2) {
+    float mn = fmaxf(m, m2);
+    float f1 = (m == -INFINITY) ? 0.f : __expf(m - mn), f2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
+    s = s * f1 + s2 * f2; ts = ts * f1 + ts2 * f2; m = mn;
+}
+__device__ __forceinline__ void better(float &v, int &i, float v2, int i2) {  // larger value, then larger index
+    if (i2 >= 0 && (i < 0 || v2 > v || (v2 == v && i2 > i))) { v = v2; i = i2; }
+}
+
+__global__ __launch_bounds__(256) void logit_step_kernel(const float *__restrict__ logits, int V, int ldl,
+                                                         DecodeState s, RuleTokens tk, int ctx, int cap, int max_new,
+                                                         int prompt_len, int mode, float *partials, unsigned *tickets,
+                                                         int32_t *pos_ptr) {
+    // nothing in this launch reads the position; every earlier kernel of the step has completed
+    if (pos_ptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *pos_ptr += 1;
+    __shared__ float sh_f[4][6];
+    __shared__ int sh_i[4][2];
+    __shared__ int sh_last;
+    const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (s.done[b]) return;
     const float *lg = logits + (long)b * ldl;
-    // candle_nn::ops::softmax: max, exp(x - max), sum, divide
-    float mx = -INFINITY;
-    for (int i = threadIdx.x; i < V; i += blockDim.x) mx = fmaxf(mx, lg[i]);
-    mx = block_max(mx, sm);
-    float se = 0.f;
-    for (int i = threadIdx.x; i < V; i += blockDim.x) se += expf(lg[i] - mx);
-    se = block_sum(se, sm);
-    if (mode == 0) {  // model.rs:293-315: no-speech probability at prompt position 0
-        if (threadIdx.x == 0) {
-            float p = expf(lg[tk.no_speech] - mx) / se;
-            s.no_speech[b] = (double)p;
-            if ((double)p > 0.6) s.done[b] = 2;
-        }
-        return;
-    }
+    const int32_t *toks = s.tokens + (long)b * ctx;
     const int n = s.n_tokens[b];
     const int have_last = s.have_last[b], last_ts = s.last_ts[b];
-    auto probs = [&](int i) { return expf(lg[i] - mx) / se; };
-    int rule, next;
-    rules_argmax(probs, V, s.tokens + (long)b * ctx, n, have_last, last_ts, s.suppress, tk, sm, rule, next);
-    if (threadIdx.x == 0) {
-        float pv = masked_value(probs(next), next, rule, s.suppress, tk, last_ts);
-        int32_t *toks = s.tokens + (long)b * ctx;
-        int nn = n;
-        if (next > tk.no_timestamps) { s.last_ts[b] = next; s.have_last[b] = 1; }  // :359-361
-        toks[nn++] = next;
-        s.sum_logprob[b] += log((double)pv);                                        // :364-365
-        int fin = 0;
-        if (nn >= cap) { toks[nn++] = tk.eot; fin = 1; }                            // :367-370
-        else if (next == tk.eot) fin = 1;                                           // :317
-        else if (max_new > 0 && nn - prompt_len >= max_new) { toks[nn++] = tk.eot; fin = 1; }  // bench knob
-        s.n_tokens[b] = nn;
-        if (fin) s.done[b] = 1;
+    const int NT = tk.no_timestamps;
+    // candidate sets: A = allowed non-timestamp tokens (or the first-token window), B = allowed timestamps
+    int kind;  // 0 FIRST, 1 SUP_TS, 2 NON_TS, 3 TEXT (NON_TS vs PAST decided at the end), 4 no-speech probe
+    if (mode == 0) kind = 4;
+    else if (!have_last) kind = 0;
+    else {
+        int l = toks[n - 1];
+        if (l > NT) kind = (n >= 2 && toks[n - 2] >= tk.eot) ? 1 : 2;
+        else kind = 3;
     }
+    const int per = (V + LSPLIT - 1) / LSPLIT, lo = part * per, hi = min(V, lo + per);
+    float m = -INFINITY, se = 0.f, ts = 0.f, tsinf = 0.f, av = -INFINITY, bv = -INFINITY;
+    int ai = -1, bi = -1;
+    // fetch the whole slice first: the statistics below are a dependent chain, the loads are not
+    constexpr int LMAX = 32;  // ceil(51866 / 8 / 256) = 26 elements per thread
+    float lv[LMAX]; unsigned char sv[LMAX];
+#pragma unroll
+    for (int u = 0; u < LMAX; u++) {
+        int i = lo + tid + 256 * u;
+        lv[u] = i < hi ? lg[i] : -INFINITY;
+        sv[u] = i < hi ? s.suppress[i] : (unsigned char)1;
+    }
+    for (int i0 = lo + 256 * LMAX; i0 < hi; i0 += 256) {  // vocabularies beyond 8 * 256 * LMAX tokens (none today)
+        int i = i0 + tid;
+        if (i < hi) { float l = lg[i]; if (l > m) { float f = __expf(m - l); se = se * f + 1.f; ts = ts * f; m = l; if (i > NT) ts += 1.f; } else { float e = __expf(l - m); se += e; if (i > NT) ts += e; } }
+    }
+    // slice maximum first, then one exp per element against it (the slice lives in registers)
+#pragma unroll
+    for (int u = 0; u < LMAX; u++) m = fmaxf(m, lv[u]);
+#pragma unroll
+    for (int u = 0; u < LMAX; u++) {
+        const int i = lo + tid + 256 * u;
+        if (i >= hi) continue;
+        const float l = lv[u];
+        const bool is_ts = i > NT;
+        const bool sup = sv[u] != 0;
+        const float e = __expf(l - m);   // softmax mass, and the timestamp mass of model.rs:263-266
+        se += e;
+        if (is_ts) { ts += e; if (sup) tsinf = 1.f; }  // p + (-inf) inside the summed slice -> the sum is -inf
+        if (kind == 0) { if (i >= tk.zero_sec && i <= tk.one_sec) better(av, ai, l, i); }
+        else if (kind == 1) { if (!is_ts && !sup) better(av, ai, l, i); }
+        else if (kind == 2) { if (is_ts && i > last_ts && !sup) better(bv, bi, l, i); }
+        else if (kind == 3) {
+            if (!is_ts && !sup) better(av, ai, l, i);
+            else if (is_ts && i > last_ts && !sup) better(bv, bi, l, i);
+        }
+    }
+    // wave reduction
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        merge_ms(m, se, ts, __shfl_xor(m, o), __shfl_xor(se, o), __shfl_xor(ts, o));
+        tsinf = fmaxf(tsinf, __shfl_xor(tsinf, o));
+        better(av, ai, __shfl_xor(av, o), __shfl_xor(ai, o));
+        better(bv, bi, __shfl_xor(bv, o), __shfl_xor(bi, o));
+    }
+    if (lane == 0) { sh_f[w][0] = m; sh_f[w][1] = se; sh_f[w][2] = ts; sh_f[w][3] = tsinf; sh_f[w][4] = av; sh_f[w][5] = bv; sh_i[w][0] = ai; sh_i[w][1] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int ww = 1; ww < 4; ww++) {
+            merge_ms(m, se, ts, sh_f[ww][0], sh_f[ww][1], sh_f[ww][2]);
+            tsinf = fmaxf(tsinf, sh_f[ww][3]);
+            better(av, ai, sh_f[ww][4], sh_i[ww][0]);
+            better(bv, bi, sh_f[ww][5], sh_i[ww][1]);
+        }
+        // publish the partial (agent-scope atomics: other workgroups may sit on another XCD/L2), then take a ticket
+        float *pp = partials + ((long)b * LSPLIT + part) * 8;
+        __hip_atomic_store(pp + 0, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 1, se, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 2, ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 3, tsinf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 4, av, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 5, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<int *>(pp) + 6, ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(reinterpret_cast<int *>(pp) + 7, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // write-through (sc1) payload, drained, then the ticket: no L2 write-back fence needed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned t = __hip_atomic_fetch_add(tickets + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = (t == LSPLIT - 1);
+    }
+    __syncthreads();
+    if (!sh_last || w != 0) return;
+    // ---- last workgroup of this sequence: combine and do the bookkeeping of model.rs:331-370 ----
+    // one L2 round trip: lane 8 q + f fetches field f of partial q, thread 0 then walks them by shuffle
+    const unsigned raw = __hip_atomic_load(reinterpret_cast<const unsigned *>(partials) + (long)b * LSPLIT * 8 + lane,
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    m = -INFINITY; se = 0.f; ts = 0.f; tsinf = 0.f; av = -INFINITY; bv = -INFINITY; ai = -1; bi = -1;
+#pragma unroll
+    for (int q = 0; q < LSPLIT; q++) {
+        float m2 = __uint_as_float(__shfl(raw, 8 * q + 0)), s2 = __uint_as_float(__shfl(raw, 8 * q + 1));
+        float t2 = __uint_as_float(__shfl(raw, 8 * q + 2)), i2 = __uint_as_float(__shfl(raw, 8 * q + 3));
+        float a2 = __uint_as_float(__shfl(raw, 8 * q + 4)), b2 = __uint_as_float(__shfl(raw, 8 * q + 5));
+        int ai2 = (int)__shfl(raw, 8 * q + 6), bi2 = (int)__shfl(raw, 8 * q + 7);
+        merge_ms(m, se, ts, m2, s2, t2);
+        tsinf = fmaxf(tsinf, i2);
+        better(av, ai, a2, ai2);
+        better(bv, bi, b2, bi2);
+    }
+    if (tid != 0) return;
+    __hip_atomic_store(tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next token
+    if (mode == 0) {  // model.rs:293-315
+        float p = expf(lg[tk.no_speech] - m) / se;
+        s.no_speech[b] = (double)p;
+        if ((double)p > 0.6) s.done[b] = 2;
+        return;
+    }
+    int next = -1; float lnext = 0.f;
+    if (kind == 0 || kind == 1) { next = ai; lnext = av; }
+    else if (kind == 2) { next = bi; lnext = bv; }
+    else {
+        float sum_ts = tsinf > 0.f ? -INFINITY : ts / se;          // probabilities, as the reference compares them
+        float max_text = ai >= 0 ? expf(av - m) / se : -INFINITY;
+        if (sum_ts >= max_text) { next = bi; lnext = bv; }          // supress_non_timestamps
+        else { next = ai; lnext = av; better(lnext, next, bv, bi); }  // supress_past_timestamps only
+    }
+    float pv;
+    if (next < 0) { next = V - 1; pv = -INFINITY; }  // every candidate masked: all -inf, last index wins (H3)
+    else pv = expf(lnext - m) / se;
+    int32_t *wt = s.tokens + (long)b * ctx;
+    int nn = n;
+    if (next > NT) { s.last_ts[b] = next; s.have_last[b] = 1; }  // :359-361
+    wt[nn++] = next;
+    s.sum_logprob[b] += log((double)pv);                          // :364-365
+    int fin = 0;
+    if (nn >= cap) { wt[nn++] = tk.eot; fin = 1; }                // :367-370
+    else if (next == tk.eot) fin = 1;                             // :317
+    else if (max_new > 0 && nn - prompt_len >= max_new) { wt[nn++] = tk.eot; fin = 1; }  // bench knob
+    s.n_tokens[b] = nn;
+    if (fin) s.done[b] = 1;
 }
 
 void launch_logit_step(const float *logits, int V, DecodeState s, RuleTokens tk, int B, int ctx, int cap,
-                       int max_new, int prompt_len, int mode, hipStream_t st) {
+                       int max_new, int prompt_len, int mode, float *partials, unsigned *tickets, int32_t *pos_ptr,
+                       hipStream_t st) {
     int ldl = (V + 63) & ~63;
-    hipLaunchKernelGGL(logit_step_kernel, dim3(B), dim3(1024), 0, st, logits, V, ldl, s, tk, ctx, cap, max_new,
-                       prompt_len, mode);
+    hipLaunchKernelGGL(logit_step_kernel, dim3(LSPLIT, B), dim3(256), 0, st, logits, V, ldl, s, tk, ctx, cap, max_new,
+                       prompt_len, mode, partials, tickets, pos_ptr);
 }
 
 __global__ __launch_bounds__(1024) void rules_only_kernel(const float *__restrict__ probs_in, float *masked_out,

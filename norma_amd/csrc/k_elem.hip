@@ -15,6 +15,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+template <bool PRELOAD>  // PRELOAD: fetch the affine parameters together with the row (latency-bound tiny M)
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, const float *__restrict__ w,
                                                         const float *__restrict__ b, half_t *__restrict__ y,
                                                         float *__restrict__ y32, int M, int d) {
@@ -23,14 +24,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
     if (row >= M) return;
     const int nv = d >> 2;
     const f32x4 *xr = reinterpret_cast<const f32x4 *>(x + (long)row * d);
-    f32x4 v[LN_MAXV];
+    const f32x4 *wr = reinterpret_cast<const f32x4 *>(w), *br = reinterpret_cast<const f32x4 *>(b);
+    f32x4 v[LN_MAXV], wv[LN_MAXV], bv[LN_MAXV];
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++) {
         int c = lane + 64 * i;
         v[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (c < nv) { v[i] = xr[c]; s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+        if (c < nv) {
+            v[i] = xr[c];
+            if (PRELOAD) { wv[i] = wr[c]; bv[i] = br[c]; }
+        }
     }
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; i++) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
     const float mean = wave_sum(s) / (float)d;
     float s2 = 0.f;
 #pragma unroll
@@ -42,12 +49,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
         }
     }
     const float inv = 1.0f / sqrtf(wave_sum(s2) / (float)d + 1e-5f);
-    const f32x4 *wr = reinterpret_cast<const f32x4 *>(w), *br = reinterpret_cast<const f32x4 *>(b);
 #pragma unroll
     for (int i = 0; i < LN_MAXV; i++) {
         int c = lane + 64 * i;
         if (c < nv) {
-            f32x4 o = (v[i] - mean) * inv * wr[c] + br[c];
+            f32x4 o = (v[i] - mean) * inv * (PRELOAD ? wv[i] : wr[c]) + (PRELOAD ? bv[i] : br[c]);
             half4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
             *reinterpret_cast<half4 *>(y + (long)row * d + 4 * c) = h;
             if (y32) *reinterpret_cast<f32x4 *>(y32 + (long)row * d + 4 * c) = o;
@@ -57,13 +63,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 
 void launch_layernorm(const float *x, const float *w, const float *b, half_t *y, float *y32, int M, int d,
                       hipStream_t st) {
-    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, w, b, y, y32, M, d);
+    if (M <= 1024) hipLaunchKernelGGL(layernorm_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, st, x, w, b, y, y32, M, d);
+    else hipLaunchKernelGGL(layernorm_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, st, x, w, b, y, y32, M, d);
 }
 
 // TextDecoder::forward input: token_embedding(x) + positional_embedding[0..T]  
 __global__ __launch_bounds__(256) void embed_kernel(const int32_t *__restrict__ tokens, int tok_stride,
                                                     const half_t *__restrict__ E, const half_t *__restrict__ P,
-                                                    float *__restrict__ x, int Tn, int t0, int d) {
+                                                    float *__restrict__ x, int Tn, int t0,
+                                                    const int32_t *__restrict__ pos_ptr, int d) {
+    if (pos_ptr) t0 = *pos_ptr;
     const int r = blockIdx.x;  // row = b * Tn + i
     const int b = r / Tn, i = r - b * Tn;
     const int tok = tokens[(long)b * tok_stride + t0 + i];
@@ -77,6 +86,6 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t *__restrict__ 
 }
 
 void launch_embed(const int32_t *tokens, int tok_stride, const half_t *E, const half_t *P, float *x, int B,
-                  int Tn, int t0, int d, hipStream_t st) {
-    hipLaunchKernelGGL(embed_kernel, dim3(B * Tn), dim3(256), 0, st, tokens, tok_stride, E, P, x, Tn, t0, d);
+                  int Tn, int t0, const int32_t *pos_ptr, int d, hipStream_t st) {
+    hipLaunchKernelGGL(embed_kernel, dim3(B * Tn), dim3(256), 0, st, tokens, tok_stride, E, P, x, Tn, t0, pos_ptr, d);
 }

@@ -6,6 +6,7 @@
 // the HIP path or returns an error.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <set>
@@ -63,6 +64,13 @@ struct nh_ctx {
     half_t *dxn = nullptr, *dq = nullptr, *datt = nullptr, *dhid = nullptr;
     DecodeState ds{};
     uint8_t *suppress = nullptr;
+    float *lpart = nullptr;
+    unsigned *ltick = nullptr;
+    float *sk_slabs = nullptr;
+    unsigned *sk_tickets = nullptr;
+    int32_t *d_pos = nullptr;  // device-side decode position (hipGraph replays read it)
+    hipGraphExec_t step_graph = nullptr;
+    int graph_key[5] = {-1, -1, -1, -1, -1};
     RuleTokens tk{};
     bool have_tokens = false;
     int VP = 0;
@@ -138,6 +146,7 @@ extern "C" void nh_destroy(nh_ctx *ctx) {
     hipSetDevice(ctx->dev);
     if (ctx->st) hipStreamSynchronize(ctx->st);
     for (void *p : ctx->allocs) hipFree(p);
+    if (ctx->step_graph) hipGraphExecDestroy(ctx->step_graph);
     if (ctx->h_done) hipHostFree(ctx->h_done);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     for (auto &e : ctx->gemm_ev) hipEventDestroy(e);
@@ -241,11 +250,11 @@ extern "C" int nh_create(int device_ordinal, const nh_config *cfg, int max_batch
     DA(dxn, half_t, (long)B * d); DA(dq, half_t, (long)B * d); DA(datt, half_t, (long)B * d); DA(dhid, half_t, (long)B * 4 * d);
     DA(ds.tokens, int32_t, (long)B * ctxlen); DA(ds.n_tokens, int32_t, B); DA(ds.done, int32_t, B);
     DA(ds.have_last, int32_t, B); DA(ds.last_ts, int32_t, B); DA(ds.sum_logprob, double, B); DA(ds.no_speech, double, B);
-    DA(ds.n_active, int32_t, 1); DA(suppress, uint8_t, V);
+    DA(ds.n_active, int32_t, 1); DA(suppress, uint8_t, V); DA(lpart, float, (long)B * 64); DA(ltick, unsigned, B); DA(d_pos, int32_t, 4); DA(sk_slabs, float, (long)SKINNY_MAX_TILES * 8 * 64 * 16); DA(sk_tickets, unsigned, SKINNY_MAX_TILES);
 #undef DA
     if (!ok) { ctx->err = "hipMalloc failed while sizing the context (out of device memory?)"; return bail(NH_ERR_NOMEM); }
     ctx->ds.suppress = ctx->suppress;
-    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_done), sizeof(int32_t) * 64, 0) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_done), sizeof(int32_t) * 128, 0) != hipSuccess) {
         ctx->err = "hipHostMalloc failed"; return bail(NH_ERR_NOMEM);
     }
     {   // encoder sinusoids, recomputed in f32 exactly as candle's sinusoids()
@@ -594,25 +603,27 @@ extern "C" int nh_encoder_output(nh_ctx *ctx, int b, float *out) {
 
 // ---- decoder ---------------------------------------------------------------------------------------------
 static void skinny(nh_ctx *ctx, const half_t *x, long ldx, const LinW &W, int R, int N, int K, int epi, void *o0, void *o1,
-                   void *o2, long ldo, int t0, int ctxlen) {
+                   void *o2, long ldo, int t0, int ctxlen, const int32_t *pos_ptr = nullptr) {
     SkinnyParams p{};
+    p.pos_ptr = pos_ptr;
     p.x = x; p.ldx = ldx; p.W = W.w; p.bias = W.b; p.R = R; p.N = N; p.K = K; p.epi = epi;
     p.out[0] = o0; p.out[1] = o1; p.out[2] = o2; p.ldo = ldo; p.d = ctx->c.d_model; p.t0 = t0; p.Tn = 1; p.ctx = ctxlen;
-    launch_skinny(p, ctx->st);
+    launch_skinny(p, ctx->sk_slabs, ctx->sk_tickets, ctx->st);
 }
 
-// one decoder position for the whole batch: consumes tokens[b][pos], leaves LN(x) in dxn (fp16) / dy32 (f32)
-static void decoder_step(nh_ctx *ctx, int pos) {
+// one decoder position for the whole batch: consumes tokens[b][pos], leaves LN(x) in dxn (fp16) / dy32 (f32).
+// pos_ptr != nullptr: the position comes from device memory (the step is being captured into a hipGraph).
+static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr) {
     const int d = ctx->c.d_model, B = ctx->cur_batch, H = ctx->c.decoder_attention_heads, C = ctx->c.max_target_positions;
-    launch_embed(ctx->ds.tokens, C, ctx->tok_emb, ctx->dec_pos, ctx->dx, B, 1, pos, d, ctx->st);
+    launch_embed(ctx->ds.tokens, C, ctx->tok_emb, ctx->dec_pos, ctx->dx, B, 1, pos, pos_ptr, d, ctx->st);
     for (auto &L : ctx->dec) {
         launch_layernorm(ctx->dx, L.ln1.w, L.ln1.b, ctx->dxn, nullptr, B, d, ctx->st);
-        skinny(ctx, ctx->dxn, d, L.qkv, B, 3 * d, d, SK_QKV, ctx->dq, L.sk, L.sv, d, pos, C);
-        launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos, ctx->st);
+        skinny(ctx, ctx->dxn, d, L.qkv, B, 3 * d, d, SK_QKV, ctx->dq, L.sk, L.sv, d, pos, C, pos_ptr);
+        launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos_ptr, ctx->st);
         skinny(ctx, ctx->datt, d, L.o, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
         launch_layernorm(ctx->dx, L.ln2.w, L.ln2.b, ctx->dxn, nullptr, B, d, ctx->st);
         skinny(ctx, ctx->dxn, d, L.cq, B, d, d, SK_F16, ctx->dq, nullptr, nullptr, d, 0, C);
-        launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, -1, ctx->st);
+        launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, nullptr, ctx->st);
         skinny(ctx, ctx->datt, d, L.co, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
         launch_layernorm(ctx->dx, L.ln3.w, L.ln3.b, ctx->dxn, nullptr, B, d, ctx->st);
         skinny(ctx, ctx->dxn, d, L.fc1, B, 4 * d, d, SK_GELU_F16, ctx->dhid, nullptr, nullptr, 4 * d, 0, C);
@@ -638,12 +649,13 @@ extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_resu
     prompt.push_back(ctx->tk.sot);
     if (ctx->tk.lang >= 0) prompt.push_back(ctx->tk.lang);
     prompt.push_back(ctx->tk.task);
-    const int P = (int)prompt.size();
+    const int P = (int)prompt.size();  // 2 or 3, so position 0 is never a generation step
     std::vector<int32_t> toks((size_t)B * C, 0), nt(B, P);
     for (int b = 0; b < B; b++) for (int i = 0; i < P; i++) toks[(size_t)b * C + i] = prompt[i];
     HIPCHK(hipMemcpyAsync(ctx->ds.tokens, toks.data(), toks.size() * 4, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipMemcpyAsync(ctx->ds.n_tokens, nt.data(), B * 4, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipMemsetAsync(ctx->ds.done, 0, B * 4, ctx->st));
+    HIPCHK(hipMemsetAsync(ctx->ltick, 0, B * 4, ctx->st));
     HIPCHK(hipMemsetAsync(ctx->ds.have_last, 0, B * 4, ctx->st));
     HIPCHK(hipMemsetAsync(ctx->ds.last_ts, 0, B * 4, ctx->st));
     HIPCHK(hipMemsetAsync(ctx->ds.sum_logprob, 0, B * 8, ctx->st));
@@ -651,25 +663,52 @@ extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_resu
     HIPCHK(hipStreamSynchronize(ctx->st));  // toks/nt are stack-owned host buffers
     HIPCHK(hipEventRecord(ctx->ev[5], ctx->st));
     int steps = 0;
-    // position pos consumes tokens[pos]; from pos = P-1 on it also emits tokens[pos+1].  The length cap
-    // (model.rs:367) forces eot once pos + 2 >= cap, so pos never exceeds cap - 2.
-    for (int pos = 0; pos <= cap - 2; pos++) {
+    // Prompt phase (eager): position pos consumes tokens[pos]; pos 0 also yields no_speech_prob
+    // (model.rs:293-305: logits at position 0 of the flush = true pass).
+    for (int pos = 0; pos < P - 1; pos++) {
         decoder_step(ctx, pos);
         steps++;
-        if (pos == 0) {  // model.rs:293-305: logits at position 0 of the prompt pass -> no_speech_prob
+        if (pos == 0) {
             logits_from_dxn(ctx, B);
-            launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 0, ctx->st);
+            launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 0, ctx->lpart, ctx->ltick, nullptr, ctx->st);
         }
-        if (pos >= P - 1) {
-            if (pos > 0) logits_from_dxn(ctx, B);
-            launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->st);
-            if (((pos - (P - 1)) & 15) == 15 || pos == cap - 2) {
-                HIPCHK(hipMemcpyAsync(ctx->h_done, ctx->ds.done, B * 4, hipMemcpyDeviceToHost, ctx->st));
-                HIPCHK(hipStreamSynchronize(ctx->st));
-                bool all = true;
-                for (int b = 0; b < B; b++) all = all && ctx->h_done[b] != 0;
-                if (all) break;
-            }
+    }
+    // Generation phase: one token per step from pos = P-1 on.  The length cap (model.rs:367) forces eot once
+    // pos + 2 >= cap, so pos never exceeds cap - 2.  The 26-launch step is captured once into a hipGraph that
+    // reads the position from device memory (the eager loop is host-launch-bound at ~5 us per tiny kernel).
+    static const bool no_graph = getenv("NORMA_HIP_NO_GRAPH") != nullptr;
+    const int key[5] = {B, ctx->S, max_new_tokens, P, 1};
+    if (!no_graph && memcmp(key, ctx->graph_key, sizeof(key)) != 0) {
+        if (ctx->step_graph) { hipGraphExecDestroy(ctx->step_graph); ctx->step_graph = nullptr; }
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(ctx->st, hipStreamCaptureModeThreadLocal));
+        decoder_step(ctx, 0, ctx->d_pos);
+        logits_from_dxn(ctx, B);
+        launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, ctx->d_pos, ctx->st);
+        HIPCHK(hipStreamEndCapture(ctx->st, &g));
+        hipError_t ge = hipGraphInstantiate(&ctx->step_graph, g, nullptr, nullptr, 0);
+        hipGraphDestroy(g);
+        if (ge != hipSuccess) return ctx->fail(NH_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge));
+        memcpy(ctx->graph_key, key, sizeof(key));
+    }
+    const int32_t first_pos = P - 1;
+    ctx->h_done[100] = first_pos;
+    HIPCHK(hipMemcpyAsync(ctx->d_pos, &ctx->h_done[100], sizeof(int32_t), hipMemcpyHostToDevice, ctx->st));
+    for (int pos = first_pos; pos <= cap - 2; pos++) {
+        if (no_graph) {
+            decoder_step(ctx, pos);
+            logits_from_dxn(ctx, B);
+            launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, nullptr, ctx->st);
+        } else {
+            HIPCHK(hipGraphLaunch(ctx->step_graph, ctx->st));
+        }
+        steps++;
+        if (((pos - first_pos) & 15) == 15 || pos == cap - 2) {
+            HIPCHK(hipMemcpyAsync(ctx->h_done, ctx->ds.done, B * 4, hipMemcpyDeviceToHost, ctx->st));
+            HIPCHK(hipStreamSynchronize(ctx->st));
+            bool all = true;
+            for (int b = 0; b < B; b++) all = all && ctx->h_done[b] != 0;
+            if (all) break;
         }
     }
     HIPCHK(hipEventRecord(ctx->ev[6], ctx->st));

@@ -54,8 +54,12 @@ struct SkinnyParams {
     void *out[3]; long ldo;
     // SK_QKV: row r = b*Tn + i  (Tn new positions per sequence); cache row = (b*ctx + t0 + i)
     int d, t0, Tn, ctx;
+    const int32_t *pos_ptr;  // when set, t0 is read from device memory (hipGraph replay of the decode step)
 };
-void launch_skinny(const SkinnyParams &p, hipStream_t st);
+#define SKINNY_MAX_TILES 512
+// slabs: f32 [SKINNY_MAX_TILES][8][64][16] scratch for cross-workgroup split-K (nullptr: never split across
+// workgroups); tickets: u32 [SKINNY_MAX_TILES], zero-initialised, self-resetting
+void launch_skinny(const SkinnyParams &p, float *slabs, unsigned *tickets, hipStream_t st);
 
 // ---- elementwise / normalisation -------------------------------------------------------------------
 // LayerNorm over rows of f32 x[M][d] -> fp16 y[M][d] (and optionally f32 y32[M][d])
@@ -63,7 +67,7 @@ void launch_layernorm(const float *x, const float *w, const float *b, half_t *y,
                       hipStream_t st);
 // decoder input: x[(b*Tn+i)][:] = E[tokens[b*tok_stride + t0 + i]][:] + P[t0+i][:]
 void launch_embed(const int32_t *tokens, int tok_stride, const half_t *E, const half_t *P, float *x, int B,
-                  int Tn, int t0, int d, hipStream_t st);
+                  int Tn, int t0, const int32_t *pos_ptr, int d, hipStream_t st);
 
 // ---- log-mel -------------------------------------------------------------------------------------------
 struct MelTables {      // device pointers, built once on the host with libm (bit-identical twiddles)
@@ -91,8 +95,9 @@ void launch_enc_attention(const half_t *q, const half_t *k, long ld, const half_
 
 // ---- decoder attention (one query row per (b, h, i)) -------------------------------------------------
 // q: fp16 [B*Tn][d]; kc,vc: fp16 [B][ctx][d]; keys visible to new row i: t0 + i + 1 (causal) or Tk (cross)
+// pos_ptr != nullptr: causal self-attention over *pos_ptr + 1 keys (device-side position)
 void launch_dec_attention(const half_t *q, const half_t *kc, const half_t *vc, half_t *out, int B, int Tn,
-                          int H, int d, int ctx, int Tk, int causal_t0, hipStream_t st);
+                          int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st);
 
 // ---- logit processor: softmax + norma rules + argmax + bookkeeping -----------------------------------
 struct DecodeState {        // all device pointers
@@ -108,8 +113,11 @@ struct DecodeState {        // all device pointers
 };
 struct RuleTokens { int sot, eot, lang, task, no_speech, no_timestamps, zero_sec, one_sec; };
 // mode 0: no-speech probe at prompt position 0; mode 1: generate a token from logits [B][V]
+// partials: f32 [B][8][8] scratch, tickets: u32 [B] zero-initialised (the kernel re-zeroes them)
+// pos_ptr != nullptr: the kernel advances the device-side position after the step
 void launch_logit_step(const float *logits, int V, DecodeState s, RuleTokens tk, int B, int ctx, int cap,
-                       int max_new, int prompt_len, int mode, hipStream_t st);
+                       int max_new, int prompt_len, int mode, float *partials, unsigned *tickets, int32_t *pos_ptr,
+                       hipStream_t st);
 // parity helper: apply rules to one already soft-maxed probability vector
 void launch_rules_only(const float *probs_in, float *masked_out, int32_t *argmax_out, const int32_t *tokens,
                        int n_tokens, int last_ts, const uint8_t *suppress, RuleTokens tk, int V, hipStream_t st);
