@@ -10,8 +10,8 @@
 // Tile: 128 (M) x 128 (N) x 64 (K) per 256-thread workgroup (4 waves as 2 x 2, 64 x 64 per wave,
 // v_mfma_f32_16x16x32_f16).  Both operands are K-contiguous, so each lane's fragment is one 16-byte
 // LDS read.  LDS image: [128 rows][8 chunks of 16 B], chunk' = chunk ^ ((row >> 1) & 7) (conflict-free
-// ds_read_b128, MI355X LDS banking), double buffered (64 KiB).  Global->LDS goes through registers
-// with the loads of tile t+1 issued before the MFMAs of tile t and written after them.
+// ds_read_b128, MI355X LDS banking), double buffered (64 KiB).  Global->LDS is global_load_lds_dwordx4
+// (LDS-DMA, no VGPR round trip, no ds_write): the loads of tile t+1 are issued before the MFMAs of tile t.
 //
 // Orientation: by default the weight rows are the MFMA "A" operand, so a lane's 4 accumulator
 // registers are 4 consecutive output COLUMNS of one row -> 8-byte fp16 / 16-byte f32 row-major
@@ -35,12 +35,21 @@ __device__ __forceinline__ const half_t *a_row_ptr(const GemmParams &p, int m) {
     return p.A + (long)b * p.a_bstride + (long)r * p.lda;
 }
 
+#ifndef NH_GEMM_GLDS
+#define NH_GEMM_GLDS 1  // 1: global_load_lds_dwordx4 straight into LDS; 0: stage through registers + ds_write_b128
+#endif
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
 template <bool SWAP>
 __device__ __forceinline__ void gemm_mainloop(const GemmParams &p, char *smem, int m0, int n0,
                                               f32x4 (&acc)[4][4]) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int wm = w >> 1, wn = w & 1;
-    // staging map: slot s = tid + 256 i (i = 0..3): row = s >> 3, chunk' = s & 7 (tid & 7 for all i)
+    // staging map: slot s = tid + 256 i (i = 0..3): row = s >> 3, chunk' = s & 7 (tid & 7 for all i).
+    // One wave-instruction covers 64 consecutive slots = 1 KiB of the LDS image, in lane order -- exactly
+    // the (wave-uniform base + lane * 16) destination of global_load_lds; the swizzle lives in the SOURCE.
     const int cq = tid & 7;
     const half_t *ag[4], *wg[4];
 #pragma unroll
@@ -52,6 +61,30 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams &p, char *smem, i
         wg[i] = p.W + (long)n * p.K + c * 8;
     }
     const int nt = p.K / BK;
+    // fragment read offsets (bytes within a tile): row r, chunk 4*ks + (lane>>4), swizzled
+    const int fr = lane & 15, fq = lane >> 4;
+    int offA[4], offB[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        int rowA = wm * 64 + 16 * j + fr;  // activation rows (m)
+        int rowB = wn * 64 + 16 * j + fr;  // weight rows (n)
+        offA[j] = rowA * 128 + ((fq ^ ((rowA >> 1) & 7)) << 4);
+        offB[j] = rowB * 128 + ((fq ^ ((rowB >> 1) & 7)) << 4);
+    }
+#if NH_GEMM_GLDS
+    const int wbase = __builtin_amdgcn_readfirstlane(w) * 1024;  // this wave's 1 KiB run inside each 4 KiB group
+    auto stage = [&](int buf, int t) {
+        char *la = smem + buf * 2 * TILE_BYTES + wbase, *lb = la + TILE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            __builtin_amdgcn_global_load_lds((gbl_void *)(ag[i] + (long)t * BK), (lds_void *)(la + 4096 * i), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(wg[i] + (long)t * BK), (lds_void *)(lb + 4096 * i), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#else
     u32x4 ra[4], rb[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -64,19 +97,13 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams &p, char *smem, i
         for (int i = 0; i < 4; i++) { la[tid + 256 * i] = ra[i]; lb[tid + 256 * i] = rb[i]; }
     }
     __syncthreads();
-    // fragment read offsets (bytes within a tile): row r, chunk 4*ks + (lane>>4), swizzled
-    const int fr = lane & 15, fq = lane >> 4;
-    int offA[4], offB[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        int rowA = wm * 64 + 16 * j + fr;  // activation rows (m)
-        int rowB = wn * 64 + 16 * j + fr;  // weight rows (n)
-        offA[j] = rowA * 128 + ((fq ^ ((rowA >> 1) & 7)) << 4);
-        offB[j] = rowB * 128 + ((fq ^ ((rowB >> 1) & 7)) << 4);
-    }
+#endif
     int cur = 0;
     for (int t = 0; t < nt; t++) {
         const bool more = (t + 1 < nt);
+#if NH_GEMM_GLDS
+        if (more) stage(cur ^ 1, t + 1);  // all waves left buf[cur^1] at the barrier that ended iteration t-1
+#else
         if (more) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
@@ -84,6 +111,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams &p, char *smem, i
                 rb[i] = *reinterpret_cast<const u32x4 *>(wg[i] + (long)(t + 1) * BK);
             }
         }
+#endif
         const char *ta = smem + cur * 2 * TILE_BYTES, *tb = ta + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
@@ -105,12 +133,16 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams &p, char *smem, i
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[j], fb[i], acc[i][j], 0, 0, 0);
                 }
         }
+#if NH_GEMM_GLDS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA for tile t+1 has landed
+#else
         if (more) {
             u32x4 *la = reinterpret_cast<u32x4 *>(smem + (cur ^ 1) * 2 * TILE_BYTES);
             u32x4 *lb = reinterpret_cast<u32x4 *>(smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES);
 #pragma unroll
             for (int i = 0; i < 4; i++) { la[tid + 256 * i] = ra[i]; lb[tid + 256 * i] = rb[i]; }
         }
+#endif
         __syncthreads();
         cur ^= 1;
     }
