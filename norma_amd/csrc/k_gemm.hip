@@ -16,6 +16,8 @@
 // Orientation: by default the weight rows are the MFMA "A" operand, so a lane's 4 accumulator
 // registers are 4 consecutive output COLUMNS of one row -> 8-byte fp16 / 16-byte f32 row-major
 // stores.  The V^T segment uses the other orientation (4 consecutive rows of one column).
+#include <stdlib.h>
+
 #include "nh_kernels.h"
 
 #define BM 128
@@ -246,7 +248,184 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// 256 x 256 tile kernel for the large encoder shapes (N % 256 == 0).
+//
+// 512 threads = 8 waves as 2 (M) x 4 (N), 128 x 64 outputs per wave (128 accumulator VGPRs).  K is
+// consumed in 32-deep stages (one v_mfma_f32_16x16x32_f16 k-step); a 4-slot LDS ring (4 x 32 KiB) is
+// filled by global_load_lds_dwordx4 THREE stages ahead of the MFMAs, so a tile has ~3 stages of matrix
+// work (~3000 cycles at 2 waves/SIMD) to arrive from L2/HBM.  Synchronisation per stage:
+//     s_waitcnt vmcnt(8)   this wave's DMA for stage s has landed (stages s+1, s+2 stay in flight)
+//     s_barrier            => every wave's DMA for stage s has landed, and every wave is done reading
+//                             stage s-1, whose slot the next DMA (stage s+3) overwrites
+// (counted vmcnt + raw s_barrier: __syncthreads() would drain the DMA queue every stage).
+// LDS image per stage and operand: [256 rows][4 chunks of 16 B], chunk' = chunk ^ (-(row >> 2) & 3):
+// conflict-free ds_read_b128 for the 16x16x32 fragment shape on 64-byte rows; the permutation is applied
+// to the per-lane global SOURCE address, the LDS destination of LDS-DMA stays lane-linear.
+// ---------------------------------------------------------------------------------------------------
+#define G2_BM 256
+#define G2_BN 256
+#define G2_BK 32
+#define G2_STAGE_BYTES 32768  // A 16 KiB + B 16 KiB
+#define G2_NSTAGE 4
+
+template <bool SWAP>
+__device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem, int m0, int n0, f32x4 (&acc)[8][4]) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    // staging: slot s = tid + 512 i (i = 0, 1): row = s >> 2, chunk' = s & 3
+    const half_t *ag[2], *wg[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        int row = (tid >> 2) + 128 * i;
+        int c = (tid & 3) ^ ((-(row >> 2)) & 3);
+        ag[i] = a_row_ptr(p, m0 + row) + c * 8;
+        wg[i] = p.W + (long)(n0 + row) * p.K + c * 8;
+    }
+    const int ns = p.K / G2_BK;
+    const int wbase = __builtin_amdgcn_readfirstlane(w) * 1024;
+    auto stage = [&](int s) {
+        char *la = smem + (s & (G2_NSTAGE - 1)) * G2_STAGE_BYTES + wbase, *lb = la + 16384;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            __builtin_amdgcn_global_load_lds((gbl_void *)(ag[i] + (long)s * G2_BK), (lds_void *)(la + 8192 * i), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(wg[i] + (long)s * G2_BK), (lds_void *)(lb + 8192 * i), 16, 0, 0);
+        }
+    };
+    // fragment offsets inside a stage: row r, chunk fq swizzled; A rows wm*128 + 16 i + fr, B rows wn*64 + 16 j + fr
+    int offA[8], offB[4];
+    const int sw = (fq ^ ((-(fr >> 2)) & 3)) << 4;
+#pragma unroll
+    for (int i = 0; i < 8; i++) offA[i] = (wm * 128 + 16 * i + fr) * 64 + sw;
+#pragma unroll
+    for (int j = 0; j < 4; j++) offB[j] = 16384 + (wn * 64 + 16 * j + fr) * 64 + sw;
+
+    stage(0);
+    if (ns > 1) stage(1);
+    if (ns > 2) stage(2);
+    for (int s = 0; s < ns; s++) {
+        const int rem = ns - 1 - s;  // stages issued beyond s (capped at 2 outstanding)
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 3 < ns) stage(s + 3);
+        const char *ts = smem + (s & (G2_NSTAGE - 1)) * G2_STAGE_BYTES;
+        half8 fa[8], fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const half8 *>(ts + offB[j]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) fa[i] = *reinterpret_cast<const half8 *>(ts + offA[i]);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[G2_NSTAGE * G2_STAGE_BYTES];
+    const int ntn = p.N / G2_BN, ntm = (p.M + G2_BM - 1) / G2_BM;
+    const int nwg = ntn * ntm;
+    int bid = blockIdx.x;
+    {
+        int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int tm = bid / ntn, tn = bid - tm * ntn;
+    const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int wm = w >> 2, wn = w & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int seg = (p.epi == EPI_F16 || p.epi == EPI_GELU_F16) ? n0 / p.seg_n : 0;
+    const bool vt = (p.epi == EPI_F16 && seg == p.vt_seg);
+    if (vt) gemm256_mainloop<false>(p, smem, m0, n0, acc);
+    else gemm256_mainloop<true>(p, smem, m0, n0, acc);
+
+    if (vt) {  // lane holds rows m = mb + 4 fq + r of column n = nb + fr
+        half_t *dst = reinterpret_cast<half_t *>(seg == 0 ? p.out[0] : seg == 1 ? p.out[1] : p.out[2]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            int n = n0 + wn * 64 + 16 * j + fr;
+            float bv = p.bias ? p.bias[n] : 0.f;
+            int nl = n - seg * p.seg_n, h = nl >> 6, dh = nl & 63;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int m = m0 + wm * 128 + 16 * i + 4 * fq;
+                if (m >= p.M) continue;
+                int b = m / p.S, s = m - b * p.S;
+                half_t *row = dst + ((long)(b * p.H + h) * NH_DH + dh) * NH_SP;
+                if (s + 3 < p.S && m + 3 < p.M) {
+                    half4 v = {(half_t)(acc[i][j][0] + bv), (half_t)(acc[i][j][1] + bv),
+                               (half_t)(acc[i][j][2] + bv), (half_t)(acc[i][j][3] + bv)};
+                    *reinterpret_cast<half4 *>(row + s) = v;
+                } else {
+                    for (int r = 0; r < 4; r++) {
+                        int mm = m + r;
+                        if (mm >= p.M) break;
+                        int bb = mm / p.S, ss = mm - bb * p.S;
+                        dst[((long)(bb * p.H + h) * NH_DH + dh) * NH_SP + ss] = (half_t)(acc[i][j][r] + bv);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    half_t *obase = reinterpret_cast<half_t *>(seg == 0 ? p.out[0] : seg == 1 ? p.out[1] : p.out[2]);
+    // SWAP orientation: lane holds columns n = nb + 4 fq + r (r = 0..3) of row m = mb + fr
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int n = n0 + wn * 64 + 16 * j + 4 * fq;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4 *>(p.bias + n);
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int m = m0 + wm * 128 + 16 * i + fr;
+            if (m >= p.M) continue;
+            f32x4 v = acc[i][j] + bv;
+            if (p.epi == EPI_F16 || p.epi == EPI_GELU_F16) {
+                if (p.epi == EPI_GELU_F16) {
+                    v[0] = gelu_tanh_f(v[0]); v[1] = gelu_tanh_f(v[1]);
+                    v[2] = gelu_tanh_f(v[2]); v[3] = gelu_tanh_f(v[3]);
+                }
+                half_t *dst = obase + out_row(p, m) * p.ldo + (n - seg * p.seg_n);
+                half4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *reinterpret_cast<half4 *>(dst) = hv;
+            } else if (p.epi == EPI_RESID_F32) {
+                float *dst = reinterpret_cast<float *>(p.out[0]) + (long)m * p.ldo + n;
+                f32x4 x = *reinterpret_cast<const f32x4 *>(dst);
+                *reinterpret_cast<f32x4 *>(dst) = x + v;
+            } else {  // EPI_CONV2_F32
+                int s = m % p.S;
+                f32x4 pe = *reinterpret_cast<const f32x4 *>(p.pos + (long)s * p.N + n);
+                f32x4 o = {gelu_tanh_f(v[0]) + pe[0], gelu_tanh_f(v[1]) + pe[1], gelu_tanh_f(v[2]) + pe[2],
+                           gelu_tanh_f(v[3]) + pe[3]};
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out[0]) + (long)m * p.ldo + n) = o;
+            }
+        }
+    }
+}
+
+static const bool g_gemm_small_only = getenv("NORMA_HIP_GEMM128") != nullptr;  // A/B switch: force the 128^2 kernel
+
 void launch_gemm(const GemmParams &p, hipStream_t st) {
+    const bool seg_ok = (p.epi != EPI_F16 && p.epi != EPI_GELU_F16) || (p.seg_n % G2_BN == 0);
+    if (!g_gemm_small_only && p.N % G2_BN == 0 && p.K % G2_BK == 0 && seg_ok && p.M >= G2_BM) {
+        int ntn = p.N / G2_BN, ntm = (p.M + G2_BM - 1) / G2_BM;
+        hipLaunchKernelGGL(gemm256_f16_kernel, dim3(ntn * ntm), dim3(512), 0, st, p);
+        return;
+    }
     int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
     hipLaunchKernelGGL(gemm_f16_kernel, dim3(ntn * ntm), dim3(256), 0, st, p);
 }
