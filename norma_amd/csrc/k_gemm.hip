@@ -268,6 +268,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
 #define G2_BK 32
 #define G2_STAGE_BYTES 32768  // A 16 KiB + B 16 KiB
 #define G2_NSTAGE 4
+// fp16 epilogues go through LDS so that every global store instruction writes whole 128/256-byte rows:
+// per wave a [128][64] image with 136-byte rows (row-major outputs) or a [64][128] image with 264-byte rows (V^T)
+#define G2_EPI_ROW 136
+#define G2_EPI_ROW_T 264
+#define G2_EPI_WAVE 17408  // max(128 * 136, 64 * 264)
+#define G2_EPI_BYTES (8 * G2_EPI_WAVE)
 
 template <bool SWAP>
 __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem, int m0, int n0, f32x4 (&acc)[8][4]) {
@@ -330,7 +336,7 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem
 }
 
 __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[G2_NSTAGE * G2_STAGE_BYTES];
+    __shared__ __attribute__((aligned(16))) char smem[G2_EPI_BYTES > G2_NSTAGE * G2_STAGE_BYTES ? G2_EPI_BYTES : G2_NSTAGE * G2_STAGE_BYTES];
     const int ntn = p.N / G2_BN, ntm = (p.M + G2_BM - 1) / G2_BM;
     const int nwg = ntn * ntm;
     int bid = blockIdx.x;
@@ -353,31 +359,76 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
     if (vt) gemm256_mainloop<false>(p, smem, m0, n0, acc);
     else gemm256_mainloop<true>(p, smem, m0, n0, acc);
 
-    if (vt) {  // lane holds rows m = mb + 4 fq + r of column n = nb + fr
+    __builtin_amdgcn_s_barrier();  // every wave has left the staging ring: LDS is free for the epilogue images
+    char *img = smem + w * G2_EPI_WAVE;
+    if (vt) {  // lane holds rows m = mb + 4 fq + r of column n = nb + fr: image [n = 64][m = 128] (V^T)
         half_t *dst = reinterpret_cast<half_t *>(seg == 0 ? p.out[0] : seg == 1 ? p.out[1] : p.out[2]);
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-            int n = n0 + wn * 64 + 16 * j + fr;
-            float bv = p.bias ? p.bias[n] : 0.f;
-            int nl = n - seg * p.seg_n, h = nl >> 6, dh = nl & 63;
+            float bv = p.bias ? p.bias[n0 + wn * 64 + 16 * j + fr] : 0.f;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                int m = m0 + wm * 128 + 16 * i + 4 * fq;
+                half4 v = {(half_t)(acc[i][j][0] + bv), (half_t)(acc[i][j][1] + bv), (half_t)(acc[i][j][2] + bv),
+                           (half_t)(acc[i][j][3] + bv)};
+                *reinterpret_cast<half4 *>(img + (16 * j + fr) * G2_EPI_ROW_T + (16 * i + 4 * fq) * 2) = v;
+            }
+        }
+        // wave-private image: same-wave LDS accesses are ordered, no barrier needed
+        // read back rows: 16 lanes x 16 B = one 256-byte row of 128 consecutive m; 4 rows per instruction
+#pragma unroll 4
+        for (int it = 0; it < 16; it++) {
+            const int nrow = 4 * it + (lane >> 4), mc = (lane & 15) * 8;
+            const half4 lo = *reinterpret_cast<const half4 *>(img + nrow * G2_EPI_ROW_T + mc * 2);
+            const half4 hi = *reinterpret_cast<const half4 *>(img + nrow * G2_EPI_ROW_T + mc * 2 + 8);
+            const int n = n0 + wn * 64 + nrow, nl = n - seg * p.seg_n, h = nl >> 6, dh = nl & 63;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                const int m = m0 + wm * 128 + mc + 4 * half;
                 if (m >= p.M) continue;
-                int b = m / p.S, s = m - b * p.S;
-                half_t *row = dst + ((long)(b * p.H + h) * NH_DH + dh) * NH_SP;
-                if (s + 3 < p.S && m + 3 < p.M) {
-                    half4 v = {(half_t)(acc[i][j][0] + bv), (half_t)(acc[i][j][1] + bv),
-                               (half_t)(acc[i][j][2] + bv), (half_t)(acc[i][j][3] + bv)};
-                    *reinterpret_cast<half4 *>(row + s) = v;
+                const half4 v = half ? hi : lo;
+                int b = m / p.S, ss = m - b * p.S;
+                if (ss + 3 < p.S && m + 3 < p.M) {
+                    *reinterpret_cast<half4 *>(dst + ((long)(b * p.H + h) * NH_DH + dh) * NH_SP + ss) = v;
                 } else {
                     for (int r = 0; r < 4; r++) {
                         int mm = m + r;
                         if (mm >= p.M) break;
-                        int bb = mm / p.S, ss = mm - bb * p.S;
-                        dst[((long)(bb * p.H + h) * NH_DH + dh) * NH_SP + ss] = (half_t)(acc[i][j][r] + bv);
+                        int bb = mm / p.S, s2 = mm - bb * p.S;
+                        dst[((long)(bb * p.H + h) * NH_DH + dh) * NH_SP + s2] = v[r];
                     }
                 }
+            }
+        }
+        return;
+    }
+    if (p.epi == EPI_F16 || p.epi == EPI_GELU_F16) {
+        // lane holds columns n = nb + 4 fq + r of row m = mb + fr: image [m = 128][n = 64] fp16
+        half_t *ob = reinterpret_cast<half_t *>(seg == 0 ? p.out[0] : seg == 1 ? p.out[1] : p.out[2]);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bv = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 64 + 16 * j + 4 * fq);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                f32x4 v = acc[i][j] + bv;
+                if (p.epi == EPI_GELU_F16) {
+                    v[0] = gelu_tanh_f(v[0]); v[1] = gelu_tanh_f(v[1]); v[2] = gelu_tanh_f(v[2]); v[3] = gelu_tanh_f(v[3]);
+                }
+                half4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                *reinterpret_cast<half4 *>(img + (16 * i + fr) * G2_EPI_ROW + (16 * j + 4 * fq) * 2) = hv;
+            }
+        }
+        // read back: 8 lanes x 16 B = one 128-byte output row segment; 8 rows per instruction
+        const int ncol = n0 + wn * 64 - seg * p.seg_n + (lane & 7) * 8;
+#pragma unroll 4
+        for (int it = 0; it < 16; it++) {
+            const int mr = 8 * it + (lane >> 3);
+            const int m = m0 + wm * 128 + mr;
+            const half4 lo = *reinterpret_cast<const half4 *>(img + mr * G2_EPI_ROW + (lane & 7) * 16);
+            const half4 hi = *reinterpret_cast<const half4 *>(img + mr * G2_EPI_ROW + (lane & 7) * 16 + 8);
+            if (m < p.M) {
+                half8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                *reinterpret_cast<half8 *>(ob + out_row(p, m) * p.ldo + ncol) = o;
             }
         }
         return;
