@@ -35,6 +35,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--max-new-tokens", type=int, default=0,
                     help="0 = reference behaviour (random weights run to the 447-token cap)")
+    ap.add_argument("--pipelines", type=int, default=int(os.environ.get("NORMA_BENCH_PIPELINES", "1")),
+                    help="batches in flight per GPU: each pipeline is its own context/stream; encoders are "
+                         "serialised by a host lock, decodes of other batches overlap them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-new-tokens", type=int, default=8)
     args = ap.parse_args()
@@ -61,16 +64,23 @@ def main():
     tk = common.tokens_for(args.model)
     B = args.batch
     t_build = time.time()
-    hm = hip.HipWhisper(cfg, device=local_rank, max_batch=B)
-    hm.set_mel_filters(assets_io.mel_filters(cfg.num_mel_bins))
-    hm.set_tokens(tk, tk.en, tk.transcribe)
+    P = max(1, args.pipelines)
+    hms = []
+    for _ in range(P):
+        h = hip.HipWhisper(cfg, device=local_rank, max_batch=B)
+        h.set_mel_filters(assets_io.mel_filters(cfg.num_mel_bins))
+        h.set_tokens(tk, tk.en, tk.transcribe)
+        hms.append(h)
+    hm = hms[0]
     want_cpu = (not args.no_cpu_baseline) and world == 1 and rank == 0
     om = None
     if want_cpu:
         from oracle import oracle as O
         om = O.OracleModel(cfg, tk, tk.en, tk.transcribe)
     for name, arr in synth.synth_weights(cfg, seed=0):  # seed-0 N(0, 0.02^2), fp16-representable
-        hm.load_tensor(name, arr.astype(np.float16))
+        a16 = arr.astype(np.float16)
+        for h in hms:
+            h.load_tensor(name, a16)
         if om is not None:
             om.set_tensor(name, arr)
     t_build = time.time() - t_build
@@ -81,22 +91,50 @@ def main():
     n_samples = [synth.N_SAMPLES] * B
     torch.cuda.synchronize()
 
-    def step(max_new):
-        return hm.transcribe_batch_device(pcm_dev.data_ptr(), n_samples, synth.N_SAMPLES, max_new)
+    import threading
+    enc_lock = threading.Lock()
+
+    def step(max_new, h=None):
+        h = h or hm
+        if P == 1:
+            return h.transcribe_batch_device(pcm_dev.data_ptr(), n_samples, synth.N_SAMPLES, max_new)
+        with enc_lock:  # one encoder at a time on the GPU; decodes of the other pipelines run beside it
+            h.logmel_device(pcm_dev.data_ptr(), n_samples, synth.N_SAMPLES)
+            h.encode()
+            h.synchronize()
+        return h.decode_greedy(max_new)
+
+    def run_steps(n, max_new):
+        """n steps spread round-robin over the pipelines (each pipeline runs its share sequentially)."""
+        if P == 1:
+            out = None
+            for _ in range(n):
+                out = step(max_new)
+            return out
+        last = [None] * P
+
+        def worker(i):
+            for _ in range(i, n, P):
+                last[i] = step(max_new, hms[i])
+        ths = [threading.Thread(target=worker, args=(i,)) for i in range(P)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        return next(r for r in last if r is not None)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        hm.synchronize()
+        for h in hms:
+            h.synchronize()
 
     hm.set_profile_gemm(True)  # two hipEventRecord per GEMM launch (~400 per step, < 0.5 % of a step)
-    for _ in range(args.warmup):
-        res = step(args.max_new_tokens)
+    res = run_steps(max(args.warmup, P if args.warmup else 0), args.max_new_tokens)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step(args.max_new_tokens)
+    res = run_steps(args.steps, args.max_new_tokens)
     barrier()
     dt = time.perf_counter() - t0
     tm = hm.timings()
@@ -130,10 +168,10 @@ def main():
             "config": {"workload": f"{args.model} fp16 batch={B} x 30 s clips per GPU, greedy decode "
                                    f"{'to the 447-token cap (seed-0 random weights never emit eot)' if args.max_new_tokens == 0 else str(args.max_new_tokens) + ' new tokens'}",
                        "batch_per_gpu": B, "clip_seconds": 30, "decode_tokens": int(np.mean([len(r['tokens']) for r in res])),
-                       "parallelism": f"chunk-dp{world}"},
+                       "parallelism": f"chunk-dp{world}", "batches_in_flight_per_gpu": P},
             "phases_ms": {k: tm[k] for k in ("mel_ms", "encoder_ms", "cross_kv_ms", "decode_ms")},
             "decode_steps": tm["decode_steps"],
-            "roofline": {"bound": "mfma", "kernel": "gemm_f16_kernel", "achieved": gemm_tflops, "peak": peak,
+            "roofline": {"bound": "mfma", "kernel": "gemm256_f16_kernel", "achieved": gemm_tflops, "peak": peak,
                          "unit": "TFLOP/s", "frac": gemm_tflops / peak, "traffic": None,
                          "launches": tm["gemm_launches"], "avg_launch_ms": tm["gemm_ms"] / max(tm["gemm_launches"], 1),
                          "flops_per_step": tm["gemm_flops"]},
@@ -160,7 +198,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    hm.close()
+    for h in hms:
+        h.close()
 
 
 if __name__ == "__main__":

@@ -11,6 +11,8 @@
 //                        :331-338), greedy argmax with Iterator::max_by(total_cmp) semantics
 //                        (:350-356, last maximum wins), log-prob bookkeeping (:359-370) -- replacing
 //                        a 207 KB D2H + a fresh [V] mask H2D + three sync scalar reads per token.
+#include <stdlib.h>
+
 #include "nh_kernels.h"
 
 __device__ __forceinline__ float gelu_tanh_d(float v) {
@@ -175,13 +177,85 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
     skinny_store(p, sum, r, n0 + 4 * nq);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Large-N variant (the 51866-row tied-embedding logits): the activations are staged ONCE per workgroup
+// into LDS as [k-step][row][4 chunks of 16 B] with chunk' = chunk ^ (-(row >> 2) & 3) (conflict-free
+// ds_read_b128 B fragments), so the only global traffic of the main loop is the weight stream:
+// every wave walks 16-row weight tiles (grid-stride), up to 10 row-segment loads in flight.
+// ---------------------------------------------------------------------------------------------------
+template <int NCB>
+__global__ __launch_bounds__(512) void skinny_lds_kernel(SkinnyParams p) {
+    extern __shared__ __attribute__((aligned(16))) char xs[];  // (K / 32) * (16 NCB) * 64 bytes
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int rows = 16 * NCB, steps = p.K >> 5;
+    for (int c = tid; c < steps * rows * 4; c += 512) {
+        const int q = c & 3, r = (c >> 2) % rows, st = (c >> 2) / rows;
+        const int rr = r < p.R ? r : p.R - 1;
+        const u32x4 v = *reinterpret_cast<const u32x4 *>(p.x + (long)rr * p.ldx + 32 * st + 8 * q);
+        *reinterpret_cast<u32x4 *>(xs + ((long)st * rows + r) * 64 + ((q ^ ((-(r >> 2)) & 3)) << 4)) = v;
+    }
+    __syncthreads();
+    const int tiles = (p.N + 15) >> 4;
+    const int nwaves = gridDim.x * 8;
+    int boff[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) boff[cb] = (16 * cb + fr) * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
+    for (int tile = blockIdx.x * 8 + w; tile < tiles; tile += nwaves) {
+        const int n0 = tile * 16;
+        int wrow = n0 + fr; if (wrow >= p.N) wrow = p.N - 1;
+        const half_t *wp = p.W + (long)wrow * p.K + 8 * fq;
+        f32x4 acc[NCB];
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int s0 = 0; s0 < steps; s0 += SK_U) {
+            half8 a[SK_U];
+#pragma unroll
+            for (int u = 0; u < SK_U; u++)
+                if (s0 + u < steps) a[u] = *reinterpret_cast<const half8 *>(wp + 32 * (s0 + u));
+#pragma unroll
+            for (int u = 0; u < SK_U; u++) {
+                if (s0 + u < steps) {
+#pragma unroll
+                    for (int cb = 0; cb < NCB; cb++) {
+                        half8 b = *reinterpret_cast<const half8 *>(xs + (long)(s0 + u) * rows * 64 + boff[cb]);
+                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b, acc[cb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            int r = 16 * cb + fr;
+            if (r < p.R) skinny_store(p, acc[cb], r, n0 + 4 * fq);
+        }
+    }
+}
+
 template <int NCB>
 static void launch_skinny_ncb(const SkinnyParams &p, float *slabs, unsigned *tickets, hipStream_t st) {
     const int tiles = (p.N + 15) / 16;
     if (tiles >= 2048) {  // the tied-embedding logits: plenty of tiles, stream full rows
-        constexpr int NT = 2;
-        int waves = (tiles + NT - 1) / NT;
-        hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 1, NT>), dim3((waves + 1) / 2), dim3(128), 0, st, p, slabs, tickets);
+        static const int nt_env = getenv("NORMA_SK_LOGITS_NT") ? atoi(getenv("NORMA_SK_LOGITS_NT")) : 0;
+        const size_t lds = (size_t)(p.K >> 5) * 16 * NCB * 64;
+        if (nt_env == 0 && NCB <= 2 && lds <= 96 * 1024) {
+            static bool attr_set[5] = {false, false, false, false, false};
+            if (!attr_set[NCB]) {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&skinny_lds_kernel<NCB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                attr_set[NCB] = true;
+            }
+            static const int nblk = getenv("NORMA_SK_LOGITS_BLOCKS") ? atoi(getenv("NORMA_SK_LOGITS_BLOCKS")) : 256;
+            hipLaunchKernelGGL((skinny_lds_kernel<NCB>), dim3(nblk), dim3(512), lds, st, p);
+        } else if (nt_env == 1) {
+            hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 1, 1>), dim3((tiles + 1) / 2), dim3(128), 0, st, p, slabs, tickets);
+        } else if (nt_env == 4) {
+            int waves = (tiles + 3) / 4;
+            hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 1, 4>), dim3((waves + 1) / 2), dim3(128), 0, st, p, slabs, tickets);
+        } else {
+            int waves = (tiles + 1) / 2;
+            hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 1, 2>), dim3((waves + 1) / 2), dim3(128), 0, st, p, slabs, tickets);
+        }
         return;
     }
     // waves per workgroup (in-block split) x KS workgroups per tile: aim at >= 2 workgroups per CU-ish

@@ -33,7 +33,10 @@ struct DecLayer { LnW ln1, ln2, ln3; LinW qkv, o, cq, ckv, co, fc1, fc2; half_t 
 
 struct nh_ctx {
     int dev = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;   // log-mel + encoder + cross K/V
+    hipStream_t sd = nullptr;   // decode loop: highest priority, so its small latency-bound kernels are dispatched ahead of
+                                // other contexts' encoder tiles when several batches are in flight on one GPU
+    hipEvent_t enc_done = nullptr;
     nh_config c{};
     int B = 1;
     std::string err;
@@ -145,11 +148,14 @@ extern "C" void nh_destroy(nh_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->dev);
     if (ctx->st) hipStreamSynchronize(ctx->st);
+    if (ctx->sd) hipStreamSynchronize(ctx->sd);
     for (void *p : ctx->allocs) hipFree(p);
     if (ctx->step_graph) hipGraphExecDestroy(ctx->step_graph);
     if (ctx->h_done) hipHostFree(ctx->h_done);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     for (auto &e : ctx->gemm_ev) hipEventDestroy(e);
+    if (ctx->enc_done) hipEventDestroy(ctx->enc_done);
+    if (ctx->sd) hipStreamDestroy(ctx->sd);
     if (ctx->st) hipStreamDestroy(ctx->st);
     delete ctx;
 }
@@ -205,7 +211,15 @@ extern "C" int nh_create(int device_ordinal, const nh_config *cfg, int max_batch
     ctx->dev = device_ordinal; ctx->c = *cfg; ctx->B = max_batch;
     auto bail = [&](int code) { g_create_error = ctx->err; nh_destroy(ctx); return code; };
     if (hipSetDevice(device_ordinal) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(NH_ERR_HIP); }
-    if (hipStreamCreate(&ctx->st) != hipSuccess) { ctx->err = "hipStreamCreate failed"; return bail(NH_ERR_HIP); }
+    {
+        int lo = 0, hi = 0;  // numerically lower = higher priority
+        hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (hipStreamCreateWithPriority(&ctx->st, hipStreamNonBlocking, lo) != hipSuccess ||
+            hipStreamCreateWithPriority(&ctx->sd, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipEventCreateWithFlags(&ctx->enc_done, hipEventDisableTiming) != hipSuccess) {
+            ctx->err = "hipStreamCreateWithPriority failed"; return bail(NH_ERR_HIP);
+        }
+    }
     for (auto &e : ctx->ev) hipEventCreate(&e);
     build_expected(ctx);
     const int B = max_batch, V = cfg->vocab_size, nm = cfg->num_mel_bins, ctxlen = cfg->max_target_positions;
@@ -586,6 +600,7 @@ extern "C" int nh_encode(nh_ctx *ctx) {
     for (auto &L : ctx->dec)
         gemm_plain(ctx, ctx->xa16, d, L.ckv, M, 2 * d, d, EPI_F16, L.ck, L.cv, nullptr, d, d, -1);
     HIPCHK(hipEventRecord(ctx->ev[4], ctx->st));
+    HIPCHK(hipEventRecord(ctx->enc_done, ctx->st));
     HIPCHK(hipGetLastError());
     ctx->have_enc = true;
     return NH_OK;
@@ -608,28 +623,28 @@ static void skinny(nh_ctx *ctx, const half_t *x, long ldx, const LinW &W, int R,
     p.pos_ptr = pos_ptr;
     p.x = x; p.ldx = ldx; p.W = W.w; p.bias = W.b; p.R = R; p.N = N; p.K = K; p.epi = epi;
     p.out[0] = o0; p.out[1] = o1; p.out[2] = o2; p.ldo = ldo; p.d = ctx->c.d_model; p.t0 = t0; p.Tn = 1; p.ctx = ctxlen;
-    launch_skinny(p, ctx->sk_slabs, ctx->sk_tickets, ctx->st);
+    launch_skinny(p, ctx->sk_slabs, ctx->sk_tickets, ctx->sd);
 }
 
 // one decoder position for the whole batch: consumes tokens[b][pos], leaves LN(x) in dxn (fp16) / dy32 (f32).
 // pos_ptr != nullptr: the position comes from device memory (the step is being captured into a hipGraph).
 static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr) {
     const int d = ctx->c.d_model, B = ctx->cur_batch, H = ctx->c.decoder_attention_heads, C = ctx->c.max_target_positions;
-    launch_embed(ctx->ds.tokens, C, ctx->tok_emb, ctx->dec_pos, ctx->dx, B, 1, pos, pos_ptr, d, ctx->st);
+    launch_embed(ctx->ds.tokens, C, ctx->tok_emb, ctx->dec_pos, ctx->dx, B, 1, pos, pos_ptr, d, ctx->sd);
     for (auto &L : ctx->dec) {
-        launch_layernorm(ctx->dx, L.ln1.w, L.ln1.b, ctx->dxn, nullptr, B, d, ctx->st);
+        launch_layernorm(ctx->dx, L.ln1.w, L.ln1.b, ctx->dxn, nullptr, B, d, ctx->sd);
         skinny(ctx, ctx->dxn, d, L.qkv, B, 3 * d, d, SK_QKV, ctx->dq, L.sk, L.sv, d, pos, C, pos_ptr);
-        launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos_ptr, ctx->st);
+        launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos_ptr, ctx->sd);
         skinny(ctx, ctx->datt, d, L.o, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
-        launch_layernorm(ctx->dx, L.ln2.w, L.ln2.b, ctx->dxn, nullptr, B, d, ctx->st);
+        launch_layernorm(ctx->dx, L.ln2.w, L.ln2.b, ctx->dxn, nullptr, B, d, ctx->sd);
         skinny(ctx, ctx->dxn, d, L.cq, B, d, d, SK_F16, ctx->dq, nullptr, nullptr, d, 0, C);
-        launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, nullptr, ctx->st);
+        launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, nullptr, ctx->sd);
         skinny(ctx, ctx->datt, d, L.co, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
-        launch_layernorm(ctx->dx, L.ln3.w, L.ln3.b, ctx->dxn, nullptr, B, d, ctx->st);
+        launch_layernorm(ctx->dx, L.ln3.w, L.ln3.b, ctx->dxn, nullptr, B, d, ctx->sd);
         skinny(ctx, ctx->dxn, d, L.fc1, B, 4 * d, d, SK_GELU_F16, ctx->dhid, nullptr, nullptr, 4 * d, 0, C);
         skinny(ctx, ctx->dhid, 4 * d, L.fc2, B, d, 4 * d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
     }
-    launch_layernorm(ctx->dx, ctx->dec_ln.w, ctx->dec_ln.b, ctx->dxn, ctx->dy32, B, d, ctx->st);
+    launch_layernorm(ctx->dx, ctx->dec_ln.w, ctx->dec_ln.b, ctx->dxn, ctx->dy32, B, d, ctx->sd);
 }
 
 static void logits_from_dxn(nh_ctx *ctx, int R) {
@@ -652,16 +667,17 @@ extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_resu
     const int P = (int)prompt.size();  // 2 or 3, so position 0 is never a generation step
     std::vector<int32_t> toks((size_t)B * C, 0), nt(B, P);
     for (int b = 0; b < B; b++) for (int i = 0; i < P; i++) toks[(size_t)b * C + i] = prompt[i];
-    HIPCHK(hipMemcpyAsync(ctx->ds.tokens, toks.data(), toks.size() * 4, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipMemcpyAsync(ctx->ds.n_tokens, nt.data(), B * 4, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipMemsetAsync(ctx->ds.done, 0, B * 4, ctx->st));
-    HIPCHK(hipMemsetAsync(ctx->ltick, 0, B * 4, ctx->st));
-    HIPCHK(hipMemsetAsync(ctx->ds.have_last, 0, B * 4, ctx->st));
-    HIPCHK(hipMemsetAsync(ctx->ds.last_ts, 0, B * 4, ctx->st));
-    HIPCHK(hipMemsetAsync(ctx->ds.sum_logprob, 0, B * 8, ctx->st));
-    HIPCHK(hipMemsetAsync(ctx->ds.no_speech, 0, B * 8, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));  // toks/nt are stack-owned host buffers
-    HIPCHK(hipEventRecord(ctx->ev[5], ctx->st));
+    HIPCHK(hipStreamWaitEvent(ctx->sd, ctx->enc_done, 0));  // the encoder and cross K/V ran on the other stream
+    HIPCHK(hipMemcpyAsync(ctx->ds.tokens, toks.data(), toks.size() * 4, hipMemcpyHostToDevice, ctx->sd));
+    HIPCHK(hipMemcpyAsync(ctx->ds.n_tokens, nt.data(), B * 4, hipMemcpyHostToDevice, ctx->sd));
+    HIPCHK(hipMemsetAsync(ctx->ds.done, 0, B * 4, ctx->sd));
+    HIPCHK(hipMemsetAsync(ctx->ltick, 0, B * 4, ctx->sd));
+    HIPCHK(hipMemsetAsync(ctx->ds.have_last, 0, B * 4, ctx->sd));
+    HIPCHK(hipMemsetAsync(ctx->ds.last_ts, 0, B * 4, ctx->sd));
+    HIPCHK(hipMemsetAsync(ctx->ds.sum_logprob, 0, B * 8, ctx->sd));
+    HIPCHK(hipMemsetAsync(ctx->ds.no_speech, 0, B * 8, ctx->sd));
+    HIPCHK(hipStreamSynchronize(ctx->sd));  // toks/nt are stack-owned host buffers
+    HIPCHK(hipEventRecord(ctx->ev[5], ctx->sd));
     int steps = 0;
     // Prompt phase (eager): position pos consumes tokens[pos]; pos 0 also yields no_speech_prob
     // (model.rs:293-305: logits at position 0 of the flush = true pass).
@@ -670,7 +686,7 @@ extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_resu
         steps++;
         if (pos == 0) {
             logits_from_dxn(ctx, B);
-            launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 0, ctx->lpart, ctx->ltick, nullptr, ctx->st);
+            launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 0, ctx->lpart, ctx->ltick, nullptr, ctx->sd);
         }
     }
     // Generation phase: one token per step from pos = P-1 on.  The length cap (model.rs:367) forces eot once
@@ -681,11 +697,11 @@ extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_resu
     if (!no_graph && memcmp(key, ctx->graph_key, sizeof(key)) != 0) {
         if (ctx->step_graph) { hipGraphExecDestroy(ctx->step_graph); ctx->step_graph = nullptr; }
         hipGraph_t g = nullptr;
-        HIPCHK(hipStreamBeginCapture(ctx->st, hipStreamCaptureModeThreadLocal));
+        HIPCHK(hipStreamBeginCapture(ctx->sd, hipStreamCaptureModeThreadLocal));
         decoder_step(ctx, 0, ctx->d_pos);
         logits_from_dxn(ctx, B);
-        launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, ctx->d_pos, ctx->st);
-        HIPCHK(hipStreamEndCapture(ctx->st, &g));
+        launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, ctx->d_pos, ctx->sd);
+        HIPCHK(hipStreamEndCapture(ctx->sd, &g));
         hipError_t ge = hipGraphInstantiate(&ctx->step_graph, g, nullptr, nullptr, 0);
         hipGraphDestroy(g);
         if (ge != hipSuccess) return ctx->fail(NH_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge));
@@ -693,33 +709,33 @@ extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_resu
     }
     const int32_t first_pos = P - 1;
     ctx->h_done[100] = first_pos;
-    HIPCHK(hipMemcpyAsync(ctx->d_pos, &ctx->h_done[100], sizeof(int32_t), hipMemcpyHostToDevice, ctx->st));
+    HIPCHK(hipMemcpyAsync(ctx->d_pos, &ctx->h_done[100], sizeof(int32_t), hipMemcpyHostToDevice, ctx->sd));
     for (int pos = first_pos; pos <= cap - 2; pos++) {
         if (no_graph) {
             decoder_step(ctx, pos);
             logits_from_dxn(ctx, B);
-            launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, nullptr, ctx->st);
+            launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, nullptr, ctx->sd);
         } else {
-            HIPCHK(hipGraphLaunch(ctx->step_graph, ctx->st));
+            HIPCHK(hipGraphLaunch(ctx->step_graph, ctx->sd));
         }
         steps++;
         if (((pos - first_pos) & 15) == 15 || pos == cap - 2) {
-            HIPCHK(hipMemcpyAsync(ctx->h_done, ctx->ds.done, B * 4, hipMemcpyDeviceToHost, ctx->st));
-            HIPCHK(hipStreamSynchronize(ctx->st));
+            HIPCHK(hipMemcpyAsync(ctx->h_done, ctx->ds.done, B * 4, hipMemcpyDeviceToHost, ctx->sd));
+            HIPCHK(hipStreamSynchronize(ctx->sd));
             bool all = true;
             for (int b = 0; b < B; b++) all = all && ctx->h_done[b] != 0;
             if (all) break;
         }
     }
-    HIPCHK(hipEventRecord(ctx->ev[6], ctx->st));
+    HIPCHK(hipEventRecord(ctx->ev[6], ctx->sd));
     std::vector<int32_t> done(B), hl(B);
     std::vector<double> slp(B), nsp(B);
-    HIPCHK(hipMemcpyAsync(toks.data(), ctx->ds.tokens, toks.size() * 4, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(nt.data(), ctx->ds.n_tokens, B * 4, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(done.data(), ctx->ds.done, B * 4, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(slp.data(), ctx->ds.sum_logprob, B * 8, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(nsp.data(), ctx->ds.no_speech, B * 8, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipMemcpyAsync(toks.data(), ctx->ds.tokens, toks.size() * 4, hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipMemcpyAsync(nt.data(), ctx->ds.n_tokens, B * 4, hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipMemcpyAsync(done.data(), ctx->ds.done, B * 4, hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipMemcpyAsync(slp.data(), ctx->ds.sum_logprob, B * 8, hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipMemcpyAsync(nsp.data(), ctx->ds.no_speech, B * 8, hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipStreamSynchronize(ctx->sd));
     HIPCHK(hipGetLastError());
     for (int b = 0; b < B; b++) {
         int32_t *t = toks.data() + (size_t)b * C;
@@ -758,6 +774,7 @@ extern "C" int nh_synchronize(nh_ctx *ctx) {
     if (!ctx) return NH_ERR_INVALID;
     hipSetDevice(ctx->dev);
     HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->sd));
     return NH_OK;
 }
 
@@ -767,6 +784,7 @@ extern "C" int nh_decoder_forward(nh_ctx *ctx, const int32_t *tokens, int T, flo
     const int B = ctx->cur_batch, C = ctx->c.max_target_positions, d = ctx->c.d_model, V = ctx->c.vocab_size;
     if (T < 1 || T > C) return ctx->fail(NH_ERR_INVALID, "nh_decoder_forward: T out of range");
     hipSetDevice(ctx->dev);
+    HIPCHK(hipStreamWaitEvent(ctx->sd, ctx->enc_done, 0));
     std::vector<int32_t> toks((size_t)B * C, 0);
     for (int b = 0; b < B; b++)
         for (int i = 0; i < T; i++) {
@@ -774,13 +792,13 @@ extern "C" int nh_decoder_forward(nh_ctx *ctx, const int32_t *tokens, int T, flo
             if (t < 0 || t >= V) return ctx->fail(NH_ERR_INVALID, "nh_decoder_forward: token id outside the vocabulary");
             toks[(size_t)b * C + i] = t;
         }
-    HIPCHK(hipMemcpyAsync(ctx->ds.tokens, toks.data(), toks.size() * 4, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipMemcpyAsync(ctx->ds.tokens, toks.data(), toks.size() * 4, hipMemcpyHostToDevice, ctx->sd));
+    HIPCHK(hipStreamSynchronize(ctx->sd));
     std::vector<float> row((size_t)B * d);
     for (int pos = 0; pos < T; pos++) {
         decoder_step(ctx, pos);
-        HIPCHK(hipMemcpyAsync(row.data(), ctx->dy32, row.size() * 4, hipMemcpyDeviceToHost, ctx->st));
-        HIPCHK(hipStreamSynchronize(ctx->st));
+        HIPCHK(hipMemcpyAsync(row.data(), ctx->dy32, row.size() * 4, hipMemcpyDeviceToHost, ctx->sd));
+        HIPCHK(hipStreamSynchronize(ctx->sd));
         for (int b = 0; b < B; b++) memcpy(hidden_out + ((size_t)b * T + pos) * d, row.data() + (size_t)b * d, sizeof(float) * d);
     }
     HIPCHK(hipGetLastError());
@@ -796,13 +814,13 @@ extern "C" int nh_final_linear(nh_ctx *ctx, const float *x, int rows, float *log
     for (int r0 = 0; r0 < rows; r0 += ctx->B) {  // the workspace holds max_batch rows at a time
         const int nr = rows - r0 < ctx->B ? rows - r0 : ctx->B;
         for (size_t i = 0; i < (size_t)nr * d; i++) h[i] = (_Float16)x[(size_t)r0 * d + i];
-        HIPCHK(hipMemcpyAsync(ctx->dxn, h.data(), (size_t)nr * d * 2, hipMemcpyHostToDevice, ctx->st));
-        HIPCHK(hipStreamSynchronize(ctx->st));
+        HIPCHK(hipMemcpyAsync(ctx->dxn, h.data(), (size_t)nr * d * 2, hipMemcpyHostToDevice, ctx->sd));
+        HIPCHK(hipStreamSynchronize(ctx->sd));
         logits_from_dxn(ctx, nr);
         for (int r = 0; r < nr; r++)
             HIPCHK(hipMemcpyAsync(logits_out + (size_t)(r0 + r) * V, ctx->logits + (size_t)r * ctx->VP, sizeof(float) * V,
-                                  hipMemcpyDeviceToHost, ctx->st));
-        HIPCHK(hipStreamSynchronize(ctx->st));
+                                  hipMemcpyDeviceToHost, ctx->sd));
+        HIPCHK(hipStreamSynchronize(ctx->sd));
     }
     HIPCHK(hipGetLastError());
     return NH_OK;
@@ -819,12 +837,12 @@ extern "C" int nh_apply_rules(nh_ctx *ctx, const float *probs, const int32_t *to
     float *tmp_out = nullptr;
     if (ctx->B == 1) { if (hipMalloc(reinterpret_cast<void **>(&tmp_out), sizeof(float) * V) != hipSuccess) return ctx->fail(NH_ERR_NOMEM, "hipMalloc"); d_out = tmp_out; }
     int32_t *d_tok = ctx->ds.tokens;
-    HIPCHK(hipMemcpyAsync(d_in, probs, sizeof(float) * V, hipMemcpyHostToDevice, ctx->st));
-    HIPCHK(hipMemcpyAsync(d_tok, tokens, sizeof(int32_t) * n_tokens, hipMemcpyHostToDevice, ctx->st));
-    launch_rules_only(d_in, d_out, ctx->ds.n_active, d_tok, n_tokens, last_timestamp, ctx->suppress, ctx->tk, V, ctx->st);
-    HIPCHK(hipMemcpyAsync(masked_out, d_out, sizeof(float) * V, hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipMemcpyAsync(argmax_out, ctx->ds.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipMemcpyAsync(d_in, probs, sizeof(float) * V, hipMemcpyHostToDevice, ctx->sd));
+    HIPCHK(hipMemcpyAsync(d_tok, tokens, sizeof(int32_t) * n_tokens, hipMemcpyHostToDevice, ctx->sd));
+    launch_rules_only(d_in, d_out, ctx->ds.n_active, d_tok, n_tokens, last_timestamp, ctx->suppress, ctx->tk, V, ctx->sd);
+    HIPCHK(hipMemcpyAsync(masked_out, d_out, sizeof(float) * V, hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipMemcpyAsync(argmax_out, ctx->ds.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipStreamSynchronize(ctx->sd));
     if (tmp_out) hipFree(tmp_out);
     HIPCHK(hipGetLastError());
     return NH_OK;
@@ -841,6 +859,7 @@ extern "C" int nh_get_timings(nh_ctx *ctx, nh_timings *out) {
     if (!ctx || !out) return NH_ERR_INVALID;
     hipSetDevice(ctx->dev);
     HIPCHK(hipStreamSynchronize(ctx->st));
+    HIPCHK(hipStreamSynchronize(ctx->sd));
     nh_timings t = ctx->tm;
     hipEventElapsedTime(&t.mel_ms, ctx->ev[0], ctx->ev[1]);
     hipEventElapsedTime(&t.encoder_ms, ctx->ev[2], ctx->ev[3]);

@@ -187,6 +187,12 @@ class HipWhisper:
         self._chk(self.L.nh_logmel(self._h, _fp(buf), _ip(ns), stride, B))
         self.batch = B
 
+    def logmel_device(self, pcm_dev_ptr: int, n_samples: Sequence[int], stride: int):
+        """PCM already resident in HBM (device pointer, f32 [batch][stride])."""
+        ns = np.asarray(n_samples, dtype=np.int32)
+        self._chk(self.L.nh_logmel_device(self._h, C.c_void_p(pcm_dev_ptr), _ip(ns), stride, len(ns)))
+        self.batch = len(ns)
+
     def get_mel(self, b: int, frames: int = N_FRAMES) -> np.ndarray:
         out = np.zeros((self.cfg.num_mel_bins, frames), dtype=np.float32)
         self._chk(self.L.nh_get_mel(self._h, b, _fp(out)))
