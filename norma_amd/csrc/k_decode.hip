@@ -31,9 +31,11 @@ __device__ __forceinline__ float gelu_tanh_d(float v) {
 // ---------------------------------------------------------------------------------------------------
 #define SK_U 10
 
-__device__ __forceinline__ void skinny_store(const SkinnyParams &p, f32x4 v, int r, int n) {
+// pre != nullptr: bias (and, for SK_RESID_F32, the residual) were fetched at kernel start into pre[0], pre[1]
+__device__ __forceinline__ void skinny_store(const SkinnyParams &p, f32x4 v, int r, int n, const f32x4 *pre = nullptr) {
     if (n >= p.N) return;
-    if (p.bias) {
+    if (pre) v += pre[0];
+    else if (p.bias) {
         if (n + 3 < p.N) v += *reinterpret_cast<const f32x4 *>(p.bias + n);
         else for (int i = 0; i < 4 && n + i < p.N; i++) v[i] += p.bias[n + i];
     }
@@ -46,7 +48,7 @@ __device__ __forceinline__ void skinny_store(const SkinnyParams &p, f32x4 v, int
     // the remaining epilogues have N % 4 == 0
     if (p.epi == SK_RESID_F32) {
         float *dst = reinterpret_cast<float *>(p.out[0]) + (long)r * p.ldo + n;
-        f32x4 x = *reinterpret_cast<const f32x4 *>(dst);
+        f32x4 x = pre ? pre[1] : *reinterpret_cast<const f32x4 *>(dst);
         *reinterpret_cast<f32x4 *>(dst) = x + v;
         return;
     }
@@ -67,6 +69,28 @@ __device__ __forceinline__ void skinny_store(const SkinnyParams &p, f32x4 v, int
     *reinterpret_cast<half4 *>(reinterpret_cast<half_t *>(p.out[0]) + (long)r * p.ldo + n) = hv;
 }
 
+// U k-steps of one wave: all loads issued back to back (never guarded: a guarded load makes hipcc drain
+// vmcnt(0) per element), then the MFMAs.  The callers cover `steps` with groups of 10, 5, 2 and 1.
+template <int U, int NT, int NCB>
+__device__ __forceinline__ void skinny_group(const half_t *const (&wp)[NT], const half_t *const (&xp)[NCB], int s0,
+                                             f32x4 (&acc)[NT][NCB]) {
+    half8 a[NT][U], b[NCB][U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) a[t][u] = *reinterpret_cast<const half8 *>(wp[t] + 32 * (s0 + u));
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) b[cb][u] = *reinterpret_cast<const half8 *>(xp[cb] + 32 * (s0 + u));
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++)
+                acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][u], b[cb][u], acc[t][cb], 0, 0, 0);
+}
+
 // HBM feeds a CU at ~24 GB/s, so a weight matrix has to be spread over ALL 256 CUs to stream at chip
 // rate: small-N layers split K across workgroups too (gridDim.y = KS).  Each workgroup publishes its
 // fp32 partial tile with write-through (sc1) stores and takes a ticket; the last one to arrive adds
@@ -82,6 +106,17 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
     const int KS = gridDim.y, ks = blockIdx.y;
     // tile base row of this wave
     const int n0 = KSPLIT == 1 ? (blockIdx.x * NW + w) * 16 * NT : blockIdx.x * 16;
+    // epilogue operands (bias, residual) of the element this thread will own: fetched now, so their latency
+    // hides under the weight stream instead of extending the dependent chain of this latency-bound kernel
+    f32x4 pre[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const bool can_pre = KSPLIT != 1 && (p.N & 3) == 0;
+    if (can_pre) {
+        const int er = tid >> 2, en = n0 + 4 * (tid & 3);
+        if (tid < 64 * NCB && er < p.R && en < p.N) {
+            if (p.bias) pre[0] = *reinterpret_cast<const f32x4 *>(p.bias + en);
+            if (p.epi == SK_RESID_F32) pre[1] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.out[0]) + (long)er * p.ldo + en);
+        }
+    }
     const int kslice = p.K / (KSPLIT * KS), kbeg = KSPLIT == 1 ? 0 : (ks * KSPLIT + w) * kslice;
     const half_t *wp[NT];
 #pragma unroll
@@ -101,27 +136,12 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) acc[t][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int steps = kslice >> 5;
-    for (int s0 = 0; s0 < steps; s0 += SK_U) {
-        half8 a[NT][SK_U], b[NCB][SK_U];
-#pragma unroll
-        for (int u = 0; u < SK_U; u++) {
-            if (s0 + u < steps) {  // wave-uniform
-#pragma unroll
-                for (int t = 0; t < NT; t++) a[t][u] = *reinterpret_cast<const half8 *>(wp[t] + 32 * (s0 + u));
-#pragma unroll
-                for (int cb = 0; cb < NCB; cb++) b[cb][u] = *reinterpret_cast<const half8 *>(xp[cb] + 32 * (s0 + u));
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < SK_U; u++) {
-            if (s0 + u < steps) {
-#pragma unroll
-                for (int t = 0; t < NT; t++)
-#pragma unroll
-                    for (int cb = 0; cb < NCB; cb++)
-                        acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][u], b[cb][u], acc[t][cb], 0, 0, 0);
-            }
-        }
+    {
+        int s0 = 0;
+        for (; s0 + 10 <= steps; s0 += 10) skinny_group<10, NT, NCB>(wp, xp, s0, acc);
+        if (s0 + 5 <= steps) { skinny_group<5, NT, NCB>(wp, xp, s0, acc); s0 += 5; }
+        for (; s0 + 2 <= steps; s0 += 2) skinny_group<2, NT, NCB>(wp, xp, s0, acc);
+        if (s0 < steps) skinny_group<1, NT, NCB>(wp, xp, s0, acc);
     }
     if (KSPLIT == 1) {
         // D[n = 4 fq + i][r = 16 cb + fr]: each lane already holds 4 consecutive features of one row
@@ -149,7 +169,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
         for (int ww = 1; ww < KSPLIT; ww++) v += red[ww][cb][src_lane];
     }
     if (KS == 1) {
-        if (owner) skinny_store(p, v, r, n0 + 4 * nq);
+        if (owner) skinny_store(p, v, r, n0 + 4 * nq, can_pre ? pre : nullptr);
         return;
     }
     // cross-workgroup split-K: slab[tile][ks][r][nq] (f32x4 as 4 write-through dwords)
@@ -174,7 +194,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
 #pragma unroll
         for (int i = 0; i < 4; i++) sum[i] += __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    skinny_store(p, sum, r, n0 + 4 * nq);
+    skinny_store(p, sum, r, n0 + 4 * nq, can_pre ? pre : nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -211,8 +231,10 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(SkinnyParams p) {
         for (int s0 = 0; s0 < steps; s0 += SK_U) {
             half8 a[SK_U];
 #pragma unroll
-            for (int u = 0; u < SK_U; u++)
-                if (s0 + u < steps) a[u] = *reinterpret_cast<const half8 *>(wp + 32 * (s0 + u));
+            for (int u = 0; u < SK_U; u++) {
+                const int sc = s0 + u < steps ? s0 + u : steps - 1;  // unconditional, clamped
+                a[u] = *reinterpret_cast<const half8 *>(wp + 32 * sc);
+            }
 #pragma unroll
             for (int u = 0; u < SK_U; u++) {
                 if (s0 + u < steps) {
@@ -263,7 +285,7 @@ static void launch_skinny_ncb(const SkinnyParams &p, float *slabs, unsigned *tic
     int ks = 1;
     auto fits = [&](int nw, int k) { return p.K % (nw * k * 32) == 0; };
     int nw = fits(4, 1) ? 4 : (fits(2, 1) ? 2 : 0);
-    if (slabs && tiles <= SKINNY_MAX_TILES) {
+    if (slabs && tiles <= SKINNY_MAX_TILES && p.K >= 2560) {  // short-K layers: the ticket round trips cost more than they buy
         while (tiles * ks < 320 && ks < 8 && nw && fits(nw, ks * 2)) ks *= 2;
         if (tiles * ks < 320 && nw == 4 && fits(2, ks * 2) && ks < 8) { nw = 2; ks *= 2; }
     }
@@ -507,33 +529,35 @@ __global__ __launch_bounds__(256) void logit_step_kernel(const float *__restrict
     __shared__ int sh_i[4][2];
     __shared__ int sh_last;
     const int b = blockIdx.y, part = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (s.done[b]) return;
     const float *lg = logits + (long)b * ldl;
+    const int per = (V + LSPLIT - 1) / LSPLIT, lo = part * per, hi = min(V, lo + per);
+    // fetch the whole slice first: the statistics below are a dependent chain, the loads are not
+    // (they are issued before the per-sequence state is even looked at -- one memory round trip for both)
+    constexpr int LMAX = 32;  // ceil(51866 / 8 / 256) = 26 elements per thread
+    float lv[LMAX]; unsigned char sv[LMAX];
+#pragma unroll
+    for (int u = 0; u < LMAX; u++) {  // unconditional (clamped) loads: a guarded load makes hipcc wait vmcnt(0) per element
+        int i = lo + tid + 256 * u;
+        int ic = i < hi ? i : hi - 1;
+        lv[u] = lg[ic];
+        sv[u] = s.suppress[ic];
+    }
     const int32_t *toks = s.tokens + (long)b * ctx;
+    const int done = s.done[b];
     const int n = s.n_tokens[b];
     const int have_last = s.have_last[b], last_ts = s.last_ts[b];
+    const double sum_lp_in = s.sum_logprob[b];  // prefetched for the bookkeeping at the end
+    const int l1 = toks[n >= 1 ? n - 1 : 0], l2 = toks[n >= 2 ? n - 2 : 0];  // unconditional: one round trip for both
+    if (done) return;
     const int NT = tk.no_timestamps;
     // candidate sets: A = allowed non-timestamp tokens (or the first-token window), B = allowed timestamps
     int kind;  // 0 FIRST, 1 SUP_TS, 2 NON_TS, 3 TEXT (NON_TS vs PAST decided at the end), 4 no-speech probe
     if (mode == 0) kind = 4;
     else if (!have_last) kind = 0;
-    else {
-        int l = toks[n - 1];
-        if (l > NT) kind = (n >= 2 && toks[n - 2] >= tk.eot) ? 1 : 2;
-        else kind = 3;
-    }
-    const int per = (V + LSPLIT - 1) / LSPLIT, lo = part * per, hi = min(V, lo + per);
+    else if (l1 > NT) kind = (n >= 2 && l2 >= tk.eot) ? 1 : 2;
+    else kind = 3;
     float m = -INFINITY, se = 0.f, ts = 0.f, tsinf = 0.f, av = -INFINITY, bv = -INFINITY;
     int ai = -1, bi = -1;
-    // fetch the whole slice first: the statistics below are a dependent chain, the loads are not
-    constexpr int LMAX = 32;  // ceil(51866 / 8 / 256) = 26 elements per thread
-    float lv[LMAX]; unsigned char sv[LMAX];
-#pragma unroll
-    for (int u = 0; u < LMAX; u++) {
-        int i = lo + tid + 256 * u;
-        lv[u] = i < hi ? lg[i] : -INFINITY;
-        sv[u] = i < hi ? s.suppress[i] : (unsigned char)1;
-    }
     for (int i0 = lo + 256 * LMAX; i0 < hi; i0 += 256) {  // vocabularies beyond 8 * 256 * LMAX tokens (none today)
         int i = i0 + tid;
         if (i < hi) { float l = lg[i]; if (l > m) { float f = __expf(m - l); se = se * f + 1.f; ts = ts * f; m = l; if (i > NT) ts += 1.f; } else { float e = __expf(l - m); se += e; if (i > NT) ts += e; } }
@@ -567,6 +591,9 @@ __global__ __launch_bounds__(256) void logit_step_kernel(const float *__restrict
         better(av, ai, __shfl_xor(av, o), __shfl_xor(ai, o));
         better(bv, bi, __shfl_xor(bv, o), __shfl_xor(bi, o));
     }
+#if defined(NH_LOGIT_DBG) && NH_LOGIT_DBG == 1
+    if (m == 12345.f) partials[0] = se + ts + av + bv + ai + bi; return;
+#endif
     if (lane == 0) { sh_f[w][0] = m; sh_f[w][1] = se; sh_f[w][2] = ts; sh_f[w][3] = tsinf; sh_f[w][4] = av; sh_f[w][5] = bv; sh_i[w][0] = ai; sh_i[w][1] = bi; }
     __syncthreads();
     if (tid == 0) {
@@ -592,6 +619,9 @@ __global__ __launch_bounds__(256) void logit_step_kernel(const float *__restrict
         sh_last = (t == LSPLIT - 1);
     }
     __syncthreads();
+#if defined(NH_LOGIT_DBG) && NH_LOGIT_DBG == 2
+    return;
+#endif
     if (!sh_last || w != 0) return;
     // ---- last workgroup of this sequence: combine and do the bookkeeping of model.rs:331-370 ----
     // one L2 round trip: lane 8 q + f fetches field f of partial q, thread 0 then walks them by shuffle
@@ -633,7 +663,7 @@ __global__ __launch_bounds__(256) void logit_step_kernel(const float *__restrict
     int nn = n;
     if (next > NT) { s.last_ts[b] = next; s.have_last[b] = 1; }  // :359-361
     wt[nn++] = next;
-    s.sum_logprob[b] += log((double)pv);                          // :364-365
+    s.sum_logprob[b] = sum_lp_in + log((double)pv);               // :364-365
     int fin = 0;
     if (nn >= cap) { wt[nn++] = tk.eot; fin = 1; }                // :367-370
     else if (next == tk.eot) fin = 1;                             // :317
