@@ -1,0 +1,67 @@
+/*
+ * norma_host.h -- C shim over the C++ host layer (norma_amd/csrc/norma_host.hpp), which mirrors norma's
+ * Whisper plugin interface (ModelDefinition / Model::transcribe, src/models/mod.rs:13-34,
+ * src/models/whisper/model.rs:55-191) on top of the kernel-level C ABI of norma_hip.h.
+ * It exists so that the host layer can be driven from tests (ctypes) exactly like the Rust crate would
+ * drive it; a Rust integration binds norma_hip.h directly and keeps this policy in Rust.
+ */
+#ifndef NORMA_HOST_H
+#define NORMA_HOST_H
+#include <stddef.h>
+#include <stdint.h>
+
+#include "norma_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* SelectedDevice kinds (src/models/mod.rs:36-43 + the new Rocm variant) */
+#define NM_DEVICE_CPU 0
+#define NM_DEVICE_CUDA 1
+#define NM_DEVICE_METAL 2
+#define NM_DEVICE_ROCM 3
+
+/* monolingual::ModelType (monolingual.rs:32-46), in declaration order without the quantized/multi variants */
+#define NM_MODEL_TINY_EN 0
+#define NM_MODEL_BASE_EN 1
+#define NM_MODEL_SMALL_EN 2
+#define NM_MODEL_MEDIUM_EN 3
+#define NM_MODEL_DISTIL_MEDIUM_EN 4
+#define NM_MODEL_DISTIL_LARGE_EN_V2 5
+#define NM_MODEL_DISTIL_LARGE_EN_V3 6
+
+typedef struct nm_definition nm_definition; /* whisper::monolingual::Definition */
+typedef struct nm_model nm_model;           /* whisper::Model */
+typedef struct nm_tensors nm_tensors;       /* the tensors a checkpoint provides (caller-owned memory) */
+
+nm_definition *nm_definition_new(int model_type, int device_kind, size_t ordinal); /* Definition::new */
+void nm_definition_free(nm_definition *d);
+int nm_definition_set_responsiveness(nm_definition *d, uint64_t period_ms); /* 0 ok, 1 = Error::Respnsivness */
+size_t nm_definition_max_chunk_len(const nm_definition *d);                 /* common_params().max_chunk_len() */
+size_t nm_definition_data_buffer_size(const nm_definition *d);
+void nm_definition_set_data_buffer_size(nm_definition *d, size_t n);
+
+nm_tensors *nm_tensors_new(void);
+void nm_tensors_add(nm_tensors *t, const char *name, int dtype, const int64_t *shape, int ndim, const void *data);
+void nm_tensors_free(nm_tensors *t);
+
+/* ModelDefinition::blocking_try_to_model; NULL on failure with the message in err */
+nm_model *nm_definition_blocking_try_to_model(const nm_definition *d, const nh_config *cfg, const nh_tokens *tk,
+                                              const int32_t *suppress, int n_suppress, const float *mel_filters,
+                                              int n_mel, const nm_tensors *tensors, char *err, int err_len);
+void nm_model_free(nm_model *m);
+
+/* Model::transcribe(&mut data, final_chunk).  out_tokens receives the token ids of every emitted segment
+ * (what the reference hands to tokenizer.decode, model.rs:147), segments separated by -1; *n_out = ints
+ * written; *buffered = samples the model keeps for the next call.  Returns 0, or 1 on a backend error. */
+int nm_model_transcribe(nm_model *m, const float *data, size_t n, int final_chunk, int32_t *out_tokens, int cap,
+                        int *n_out, size_t *buffered, char *err, int err_len);
+/* DecodingResult of the last decoded slice + whether the reference would have entered its sampled fallback */
+void nm_model_last_result(const nm_model *m, double *avg_logprob, double *no_speech_prob, int *needed_fallback,
+                          int *n_tokens);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

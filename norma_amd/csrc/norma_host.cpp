@@ -1,0 +1,78 @@
+// norma_host.cpp -- C shim (include/norma_host.h) over norma_host.hpp.
+#include "../../include/norma_host.h"
+
+#include <string.h>
+
+#include "norma_host.hpp"
+
+using namespace norma;
+using namespace norma::whisper;
+
+struct nm_definition { Definition def; };
+struct nm_model { Model *m; };
+struct nm_tensors { std::vector<TensorView> v; };
+
+static void put_err(char *err, int n, const std::string &s) {
+    if (!err || n <= 0) return;
+    strncpy(err, s.c_str(), (size_t)n - 1);
+    err[n - 1] = 0;
+}
+
+extern "C" {
+
+nm_definition *nm_definition_new(int model_type, int device_kind, size_t ordinal) {
+    SelectedDevice dev;
+    dev.kind = (SelectedDevice::Kind)device_kind;
+    dev.ordinal = ordinal;
+    return new nm_definition{Definition((ModelType)model_type, dev)};
+}
+void nm_definition_free(nm_definition *d) { delete d; }
+int nm_definition_set_responsiveness(nm_definition *d, uint64_t period_ms) { return d->def.set_responsiveness(period_ms) ? 1 : 0; }
+size_t nm_definition_max_chunk_len(const nm_definition *d) { return d->def.common_params().max_chunk_len(); }
+size_t nm_definition_data_buffer_size(const nm_definition *d) { return d->def.common_params().data_buffer_size(); }
+void nm_definition_set_data_buffer_size(nm_definition *d, size_t n) { d->def.set_data_buffer_size(n); }
+
+nm_tensors *nm_tensors_new(void) { return new nm_tensors(); }
+void nm_tensors_add(nm_tensors *t, const char *name, int dtype, const int64_t *shape, int ndim, const void *data) {
+    t->v.push_back(TensorView{name, dtype, std::vector<int64_t>(shape, shape + ndim), data});
+}
+void nm_tensors_free(nm_tensors *t) { delete t; }
+
+nm_model *nm_definition_blocking_try_to_model(const nm_definition *d, const nh_config *cfg, const nh_tokens *tk,
+                                              const int32_t *suppress, int n_suppress, const float *mel_filters,
+                                              int n_mel, const nm_tensors *tensors, char *err, int err_len) {
+    Model *m = nullptr;
+    std::vector<int32_t> sup(suppress, suppress + (n_suppress > 0 ? n_suppress : 0));
+    Error e = d->def.blocking_try_to_model(*cfg, *tk, sup, mel_filters, n_mel, tensors->v, &m);
+    if (e) { put_err(err, err_len, e.message); return nullptr; }
+    return new nm_model{m};
+}
+void nm_model_free(nm_model *m) { if (m) { delete m->m; delete m; } }
+
+int nm_model_transcribe(nm_model *m, const float *data, size_t n, int final_chunk, int32_t *out_tokens, int cap,
+                        int *n_out, size_t *buffered, char *err, int err_len) {
+    std::vector<float> v(data, data + n);
+    std::vector<Segment> segs;
+    Error e = m->m->transcribe(v, final_chunk != 0, segs);
+    if (buffered) *buffered = m->m->buffered_samples();
+    if (e) { put_err(err, err_len, e.message); return 1; }
+    int w = 0;
+    for (const auto &s : segs) {
+        if (w + (int)s.tokens.size() + 1 > cap) { put_err(err, err_len, "output buffer too small"); return 1; }
+        for (uint32_t t : s.tokens) out_tokens[w++] = (int32_t)t;
+        out_tokens[w++] = -1;
+    }
+    if (n_out) *n_out = w;
+    return 0;
+}
+
+void nm_model_last_result(const nm_model *m, double *avg_logprob, double *no_speech_prob, int *needed_fallback,
+                          int *n_tokens) {
+    const DecodingResult &r = m->m->last_result();
+    if (avg_logprob) *avg_logprob = r.avg_logprob;
+    if (no_speech_prob) *no_speech_prob = r.no_speech_prob;
+    if (needed_fallback) *needed_fallback = m->m->last_needed_fallback() ? 1 : 0;
+    if (n_tokens) *n_tokens = (int)r.tokens.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,254 @@
+// norma_host.hpp -- C++ host layer above the C ABI (include/norma_hip.h) that mirrors norma's plugin
+// interface for the Whisper path: same names, argument meaning and error behaviour as the Rust items
+// it stands in for (the reference is compiled Rust; no Rust toolchain exists in this environment, so
+// the host side is written in C++; the Rust binding itself is in INTEGRATION.md).
+//
+//   reference (MikeIvanichev/norma @ 2024_10_08)                 here
+//   ------------------------------------------------------------ ---------------------------------
+//   models::SelectedDevice              src/models/mod.rs:36-55   norma::SelectedDevice (+ Rocm(ord))
+//   models::CommonModelParams           src/models/mod.rs:58-117  norma::CommonModelParams
+//   models::ModelDefinition / Model     src/models/mod.rs:13-34   norma::whisper::Definition / Model
+//   whisper::Error                      whisper/mod.rs:64-84      norma::whisper::Error
+//   whisper::monolingual::ModelType     monolingual.rs:32-111     norma::whisper::ModelType
+//   whisper::Model::transcribe          model.rs:55-159           Model::transcribe
+//   Model::decode_with_fallback (t=0)   model.rs:164-191          Model::decode_with_fallback
+//   SliceExt::inclusive_boxed_by        src/utils.rs:22-76        norma::inclusive_boxed_by
+//
+// Text decoding needs a tokenizer (`tokenizers` crate in the reference, model.rs:147); none is
+// available offline, so transcribe() returns the token ids of each segment and, when a detokenizer
+// callback is installed, the text as well.
+#pragma once
+#include <stdint.h>
+
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/norma_hip.h"
+
+namespace norma {
+
+// ---- src/utils.rs:22-76 ----------------------------------------------------------------------------
+// Consecutive sub-slices that start AND end (inclusive) on an element matching pred.
+template <typename T, typename P>
+std::vector<std::pair<size_t, size_t>> inclusive_boxed_by(const std::vector<T> &v, P pred) {
+    std::vector<std::pair<size_t, size_t>> out;  // [begin, end)
+    size_t base = 0;
+    while (base < v.size()) {
+        size_t s = base;
+        while (s < v.size() && !pred(v[s])) s++;
+        if (s >= v.size()) break;
+        size_t e = s + 1;
+        while (e < v.size() && !pred(v[e])) e++;
+        if (e >= v.size()) break;
+        out.emplace_back(s, e + 1);
+        base = e + 1;
+    }
+    return out;
+}
+
+// ---- src/models/mod.rs:36-55 ------------------------------------------------------------------------
+struct SelectedDevice {
+    enum Kind { Cpu, Cuda, Metal, Rocm } kind = Cpu;  // Default = Cpu
+    size_t ordinal = 0;
+    static SelectedDevice cpu() { return {}; }
+    static SelectedDevice cuda(size_t n) { return {Cuda, n}; }
+    static SelectedDevice metal() { return {Metal, 0}; }
+    static SelectedDevice rocm(size_t n) { return {Rocm, n}; }  // NEW: MI355X ordinal, selects the HIP backend
+};
+
+// ---- src/models/mod.rs:58-117 -----------------------------------------------------------------------
+class CommonModelParams {
+    static constexpr size_t MIN_CHUNK_LEN = 100, MIN_STRING_BUF_SIZE = 1;
+    size_t max_chunk_len_, data_buffer_size_, string_buffer_size_;
+  public:
+    CommonModelParams(size_t max_chunk_len, size_t data_buffer_size, size_t string_buffer_size)
+        : max_chunk_len_(std::max(max_chunk_len, MIN_CHUNK_LEN)), data_buffer_size_(data_buffer_size + 2),
+          string_buffer_size_(std::max(string_buffer_size, MIN_STRING_BUF_SIZE)) {}
+    size_t max_chunk_len() const { return std::max(max_chunk_len_, MIN_CHUNK_LEN); }
+    size_t data_buffer_size() const { return data_buffer_size_; }
+    size_t string_buffer_size() const { return string_buffer_size_; }
+    void set_max_chunk_len(size_t v) { max_chunk_len_ = std::max(v, MIN_CHUNK_LEN); }
+    void set_data_buffer_size(size_t v) { data_buffer_size_ = v + 2; }
+    void set_string_buffer_size(size_t v) { string_buffer_size_ = std::max(v, MIN_STRING_BUF_SIZE); }
+};
+
+namespace whisper {
+
+constexpr uint32_t SAMPLE_RATE = 16000;       // Model::SAMPLE_RATE (model.rs:52)
+constexpr size_t N_SAMPLES = NH_N_SAMPLES;    // candle m::N_SAMPLES
+constexpr double NO_SPEECH_THRESHOLD = 0.6, LOGPROB_THRESHOLD = -1.0;
+
+// whisper/mod.rs:64-84 (variants that can occur on this path) + the run-time error of model.rs:44-46
+struct Error {
+    enum Kind { None, TokenId, Backend /* TranscriberError */, MelBins, Respnsivness, UnsupportedDevice } kind = None;
+    std::string message;
+    explicit operator bool() const { return kind != None; }
+};
+
+enum class VocabVersion { V1, V2, EnV1, EnV2 };  // whisper/mod.rs:57-62
+
+// monolingual.rs:32-46 (ids/revisions are download metadata, out of scope offline)
+enum class ModelType { TinyEn, BaseEn, SmallEn, MediumEn, DistilMediumEn, DistilLargeEnV2, DistilLargeEnV3 };
+inline VocabVersion vocab_version(ModelType m) {  // monolingual.rs:99-110
+    switch (m) {
+        case ModelType::DistilMediumEn: case ModelType::DistilLargeEnV2: return VocabVersion::V1;
+        case ModelType::DistilLargeEnV3: return VocabVersion::V2;
+        default: return VocabVersion::EnV1;
+    }
+}
+
+struct DecodingResult {  // model.rs:494-499
+    std::vector<uint32_t> tokens;
+    double avg_logprob = 0, no_speech_prob = 0, compression_ratio = 0;
+};
+
+struct Segment { std::vector<uint32_t> tokens; std::string text; };  // one `<ts> text <ts|eot>` span, model.rs:100-149
+
+// The loaded model: owns one nh_ctx (batch 1, like the reference) and the carried-over PCM buffer.
+class Model {
+  public:
+    typedef float Data;                               // Model::Data = f32 (model.rs:49)
+    Model(nh_ctx *ctx, nh_config cfg, nh_tokens tk) : ctx_(ctx), cfg_(cfg), tk_(tk) {}
+    Model(Model &&o) noexcept : ctx_(o.ctx_), cfg_(o.cfg_), tk_(o.tk_), buf_(std::move(o.buf_)), detok_(std::move(o.detok_)) { o.ctx_ = nullptr; }
+    Model(const Model &) = delete;
+    ~Model() { if (ctx_) nh_destroy(ctx_); }
+
+    void set_detokenizer(std::function<std::string(const uint32_t *, size_t)> f) { detok_ = std::move(f); }
+    size_t buffered_samples() const { return buf_.size(); }
+
+    // Model::transcribe (model.rs:55-159).  `data` is consumed (swapped/appended into the model's buffer).
+    // Returns an Error with kind != None on a backend failure (the reference's TranscriberError, which
+    // ends the transcriber thread: src/lib.rs:466-477).
+    Error transcribe(std::vector<float> &data, bool final_chunk, std::vector<Segment> &out, std::string *text = nullptr) {
+        if (buf_.empty()) std::swap(buf_, data);                      // :60-64
+        else { buf_.insert(buf_.end(), data.begin(), data.end()); data.clear(); }
+        bool stop = false;
+        while (!buf_.empty() && !stop) {                              // 'new_chunk, :68
+            const size_t slice_len = std::min(buf_.size(), N_SAMPLES);
+            DecodingResult dr;
+            bool have = false;
+            Error e = decode_with_fallback(buf_.data(), slice_len, dr, have);
+            if (e) return e;
+            if (!have) { drain(slice_len); continue; }                // :90-93
+            if (dr.no_speech_prob > NO_SPEECH_THRESHOLD && dr.avg_logprob < LOGPROB_THRESHOLD) { drain(slice_len); continue; }  // :95-98
+            bool drained = false, any = false;
+            for (auto seg : inclusive_boxed_by(dr.tokens, [&](uint32_t t) { return t > (uint32_t)tk_.no_timestamps || t == (uint32_t)tk_.eot; })) {
+                any = true;
+                const uint32_t *tok = dr.tokens.data() + seg.first;
+                const size_t n = seg.second - seg.first;
+                const uint32_t s_timestamp = tok[0] - (uint32_t)tk_.no_timestamps - 1;  // :103
+                const uint32_t e_tok = tok[n - 1];
+                if (e_tok == (uint32_t)tk_.eot) {
+                    if (s_timestamp == 0 || final_chunk) {
+                        if (slice_len == N_SAMPLES || final_chunk) { drain(slice_len); drained = true; }  // :109-115
+                        else { stop = true; break; }                                                     // :116-123
+                    } else {
+                        const size_t pre = buf_.size();
+                        drain(std::min((size_t)s_timestamp * 320, slice_len));                           // :125-127
+                        drained = true;
+                        if (pre > slice_len) break;                                                       // :129-136
+                        stop = true; break;                                                               // :138-143
+                    }
+                }
+                Segment sg;
+                sg.tokens.assign(tok + 1, tok + n - 1);                                                   // tokens[1..len-1], :147
+                if (detok_) { sg.text = detok_(sg.tokens.data(), sg.tokens.size()); if (text) *text += sg.text; }
+                out.push_back(std::move(sg));
+            }
+            // H1: a result without any drained segment (e.g. the no-speech early return, whose
+            // tokens hold no timestamp) leaves `buf` untouched in the reference, which then spins forever on the
+            // same slice.  Deviation: drain the slice and go on.
+            if (!stop && !drained && !any) drain(slice_len);
+            else if (!stop && !drained) drain(slice_len);
+        }
+        if (final_chunk) {                                            // :153-156
+            int rc = nh_reset(ctx_);
+            if (rc) return backend_error();
+        }
+        return Error{};
+    }
+
+    // decode_with_fallback (model.rs:164-191) restricted to the deterministic t = 0.0 pass: the reference's
+    // fallback temperatures sample with an entropy-seeded RNG (monolingual.rs:439) and cannot be reproduced.
+    Error decode_with_fallback(const float *pcm, size_t n, DecodingResult &dr, bool &have) {
+        int32_t ns = (int32_t)n;
+        if (nh_logmel(ctx_, pcm, &ns, (int64_t)n, 1)) return backend_error();   // audio::pcm_to_mel + narrow, :74-88
+        if (nh_encode(ctx_)) return backend_error();                            // encoder_forward(mel, true), :168
+        std::vector<int32_t> toks(cfg_.max_target_positions);
+        nh_decode_result r{};
+        if (nh_decode_greedy(ctx_, toks.data(), &r, 0)) return backend_error(); // decode(audio_features, 0.0), :176
+        dr.tokens.assign(toks.begin(), toks.begin() + r.n_tokens);
+        dr.avg_logprob = r.avg_logprob; dr.no_speech_prob = r.no_speech_prob;
+        dr.compression_ratio = 0.0 / 0.0;                                        // f64::NAN, :387
+        last_ = dr;
+        // :177-187 -- accept unless avg_logprob < -1 (compression_ratio is NaN, so that test is always false);
+        // a result that would need the sampled fallback is still returned (have = true) and flagged.
+        needs_fallback_ = dr.avg_logprob < LOGPROB_THRESHOLD && !(dr.no_speech_prob > NO_SPEECH_THRESHOLD);
+        have = true;
+        return Error{};
+    }
+    const DecodingResult &last_result() const { return last_; }
+    bool last_needed_fallback() const { return needs_fallback_; }
+
+  private:
+    void drain(size_t n) { buf_.erase(buf_.begin(), buf_.begin() + (long)std::min(n, buf_.size())); }
+    Error backend_error() const { return Error{Error::Backend, nh_last_error(ctx_)}; }
+    nh_ctx *ctx_;
+    nh_config cfg_;
+    nh_tokens tk_;
+    std::vector<float> buf_;
+    std::function<std::string(const uint32_t *, size_t)> detok_;
+    DecodingResult last_;
+    bool needs_fallback_ = false;
+};
+
+// One tensor handed to the loader (HF name, f32 or f16 data) -- stands in for the safetensors mmap of
+// monolingual.rs:237-239; the caller decides where the bytes come from.
+struct TensorView { std::string name; int dtype; std::vector<int64_t> shape; const void *data; };
+
+// monolingual::Definition (monolingual.rs:113-174, 176-452).  The hf-hub download is out of scope (no
+// network); the loaded pieces (config, special-token ids, suppress list, mel filters, tensors) are passed in.
+class Definition {
+  public:
+    Definition(ModelType model, SelectedDevice device)  // Definition::new, monolingual.rs:124-130
+        : model_(model), device_(device), common_params_(SAMPLE_RATE * 25, 3, 3) {}
+    const CommonModelParams &common_params() const { return common_params_; }
+    Error set_responsiveness(uint64_t period_ms) {      // monolingual.rs:147-156
+        if (period_ms >= 1000 && period_ms <= 30000) { common_params_.set_max_chunk_len((size_t)SAMPLE_RATE * period_ms / 1000); return Error{}; }
+        return Error{Error::Respnsivness, "The respnsivness must be over 1 second and under 30"};
+    }
+    void set_data_buffer_size(size_t n) { common_params_.set_data_buffer_size(n); }
+    void set_string_buffer_size(size_t n) { common_params_.set_string_buffer_size(n); }
+    ModelType model() const { return model_; }
+
+    // blocking_try_to_model (monolingual.rs:320-451) for SelectedDevice::Rocm.
+    Error blocking_try_to_model(const nh_config &cfg, const nh_tokens &tk, const std::vector<int32_t> &suppress,
+                                const float *mel_filters, int n_mel, const std::vector<TensorView> &tensors,
+                                Model **out) const {
+        if (device_.kind != SelectedDevice::Rocm)
+            return Error{Error::UnsupportedDevice, "this build only implements SelectedDevice::Rocm(ord)"};
+        if (n_mel != 80 && n_mel != 128)   // whisper::Error::MelBins, monolingual.rs:351-355
+            return Error{Error::MelBins, "Unexpected number of mel bins (num_mel_bins), got: " + std::to_string(n_mel)};
+        nh_ctx *ctx = nullptr;
+        if (nh_create((int)device_.ordinal, &cfg, 1, &ctx)) return Error{Error::Backend, nh_last_error(nullptr)};
+        auto fail = [&]() { Error e{Error::Backend, nh_last_error(ctx)}; nh_destroy(ctx); return e; };
+        for (const auto &t : tensors)
+            if (nh_load_tensor(ctx, t.name.c_str(), t.dtype, t.shape.data(), (int)t.shape.size(), t.data)) return fail();
+        if (nh_missing_tensors(ctx) != 0) { nh_destroy(ctx); return Error{Error::Backend, "checkpoint is missing tensors"}; }
+        if (nh_set_mel_filters(ctx, mel_filters, n_mel)) return fail();
+        if (nh_set_tokens(ctx, &tk, suppress.data(), (int)suppress.size())) return fail();
+        *out = new Model(ctx, cfg, tk);
+        return Error{};
+    }
+
+  private:
+    ModelType model_;
+    SelectedDevice device_;
+    CommonModelParams common_params_;
+};
+
+}  // namespace whisper
+}  // namespace norma

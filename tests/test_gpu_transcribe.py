@@ -1,0 +1,87 @@
+"""GPU: the C++ host layer's Model::transcribe (buffering, 30 s windows, segment cutting, seek by
+timestamps, final_chunk) against the oracle's restatement of src/models/whisper/model.rs:55-159 on
+scripted fixtures (peaked decodes, so the emitted segments are unambiguous)."""
+import numpy as np
+import pytest
+
+import common
+from norma_amd import assets_io, config, host, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(script, name="test-d128"):
+    cfg = config.preset(name)
+    tk = common.tokens_for(name)
+    over = common.scripted_overrides(cfg, tk, script)
+    om = common.build_oracle(cfg, tk, overrides=over)
+    d = host.Definition(host.ModelType.TinyEn, host.SelectedDevice.Rocm(0))
+    model = d.blocking_try_to_model(cfg, tk, tk.en, tk.transcribe,
+                                    ((n, a.astype(np.float16)) for n, a in synth.synth_weights(cfg, 0, over)))
+    return cfg, tk, om, model, assets_io.mel_filters(cfg.num_mel_bins)
+
+
+def test_per_chunk_semantics_final_chunk_drains_and_emits_all_segments():
+    tk = common.tokens_for("test-d128")
+    script = common.transcript_script(tk, n_segments=4, words_per_segment=5)
+    cfg, tk, om, model, filt = _pair(script)
+    pcm = synth.synth_pcm(0)
+    segs = model.transcribe(pcm, final_chunk=True)
+    ref, buf, info = om.transcribe(pcm, filt, final_chunk=True)
+    assert segs == ref and len(segs) == 4
+    assert model.buffered_samples == len(buf) == 0
+    last = model.last_result()
+    assert abs(last["avg_logprob"] - info["avg_logprob"]) < 5e-3 and not last["needed_fallback"]
+    model.close()
+
+
+def test_streaming_seek_keeps_the_unfinished_segment_for_the_next_call():
+    """Not final, 25 s chunk (the reference's default max_chunk_len), last segment opens at a non-zero
+    timestamp: the buffer is drained up to that timestamp (320 samples per 0.02 s unit, model.rs:125-127) and
+    the segment's text is withheld until more audio arrives."""
+    tk = common.tokens_for("test-d128")
+    script = common.transcript_script(tk, n_segments=3, words_per_segment=4)
+    cfg, tk, om, model, filt = _pair(script)
+    pcm = synth.synth_pcm(1, 400000)
+    segs = model.transcribe(pcm, final_chunk=False)
+    ref, buf, _ = om.transcribe(pcm, filt, final_chunk=False)
+    assert segs == ref
+    assert model.buffered_samples == len(buf) and 0 < len(buf) < 400000
+    # the second call appends to the carried-over buffer (model.rs:60-64) and, being final, drains everything
+    more = synth.synth_pcm(2, 200000)
+    segs2 = model.transcribe(more, final_chunk=True)
+    ref2, buf2, _ = om.transcribe(more, filt, final_chunk=True, buf=buf)
+    assert segs2 == ref2 and model.buffered_samples == len(buf2) == 0
+    model.close()
+
+
+def test_long_buffer_is_cut_into_30s_windows():
+    tk = common.tokens_for("test-d128")
+    script = [tk.zero_sec] + [700, 800, 900] + [tk.eot]   # one segment starting at 0.00 -> the whole window is consumed
+    cfg, tk, om, model, filt = _pair(script)
+    pcm = np.concatenate([synth.synth_pcm(3), synth.synth_pcm(4, 240000)])   # 45 s
+    segs = model.transcribe(pcm, final_chunk=True)
+    ref, buf, info = om.transcribe(pcm, filt, final_chunk=True)
+    assert info["n_slices"] == 2 and segs == ref == [[700, 800, 900]] * 2
+    assert model.buffered_samples == 0
+    model.close()
+
+
+def test_no_speech_result_drains_instead_of_spinning_forever():
+    """Hazard H1: the reference would loop forever here (model.rs:308-315 + :95-98 + :100); both sides drain."""
+    tk = common.tokens_for("test-d128")
+    cfg = config.preset("test-d128")
+    over = common.scripted_overrides(cfg, tk, [tk.zero_sec, 500, tk.eot])
+    pos = over["model.decoder.embed_positions.weight"].copy()
+    pos[0] += np.float32(4.0) * over["model.decoder.embed_tokens.weight"][tk.no_speech]
+    over["model.decoder.embed_positions.weight"] = pos.astype(np.float16).astype(np.float32)
+    om = common.build_oracle(cfg, tk, overrides=over)
+    d = host.Definition(host.ModelType.TinyEn, host.SelectedDevice.Rocm(0))
+    model = d.blocking_try_to_model(cfg, tk, tk.en, tk.transcribe,
+                                    ((n, a.astype(np.float16)) for n, a in synth.synth_weights(cfg, 0, over)))
+    pcm = synth.synth_pcm(0, 320000)
+    segs = model.transcribe(pcm, final_chunk=False)
+    ref, buf, info = om.transcribe(pcm, assets_io.mel_filters(80), final_chunk=False)
+    assert segs == ref == [] and model.buffered_samples == len(buf) == 0
+    assert model.last_result()["no_speech_prob"] > 0.6
+    model.close()
