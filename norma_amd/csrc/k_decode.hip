@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(SkinnyParams p) {
 #pragma unroll
             for (int u = 0; u < SK_U; u++) {
                 const int sc = s0 + u < steps ? s0 + u : steps - 1;  // unconditional, clamped
-                a[u] = *reinterpret_cast<const half8 *>(wp + 32 * sc);
+                a[u] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(wp + 32 * sc));  // 133 MB read once per token
             }
 #pragma unroll
             for (int u = 0; u < SK_U; u++) {
@@ -344,8 +344,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict_
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             int j = j0 + 8 * u + slot; if (j >= kend) j = kend - 1;
-            kk[u] = *reinterpret_cast<const half8 *>(kb + (long)j * d);
-            vv[u] = *reinterpret_cast<const half8 *>(vb + (long)j * d);
+            // streamed once per token: non-temporal, so the K/V stream (491 MB per step at b32) does not evict the
+            // decoder weights from the Infinity Cache between tokens
+            kk[u] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(kb + (long)j * d));
+            vv[u] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(vb + (long)j * d));
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {

@@ -268,6 +268,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
 #define G2_BK 32
 #define G2_STAGE_BYTES 32768  // A 16 KiB + B 16 KiB
 #define G2_NSTAGE 4
+#define G2_GM 4
 // fp16 epilogues go through LDS so that every global store instruction writes whole 128/256-byte rows:
 // per wave a [128][64] image with 136-byte rows (row-major outputs) or a [64][128] image with 264-byte rows (V^T)
 #define G2_EPI_ROW 136
@@ -344,7 +345,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
         int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    const int tm = bid / ntn, tn = bid - tm * ntn;
+    // grouped order inside the XCD's run of tiles: G2_GM M-panels x all N-tiles at a time, N outer / M inner, so the
+    // ~32 tiles an XCD has in flight are 4 M-panels x 8 N-tiles: the A panels (4 x 256 x K) stay in that XCD's 4 MiB
+    // L2 for the whole N sweep and each streamed W tile is shared by 4 workgroups (PMC: W was re-fetched once per
+    // M-panel from the Infinity Cache with the plain M-major order)
+    int tm, tn;
+    {
+        const int per_group = G2_GM * ntn;
+        const int g = bid / per_group, r = bid - g * per_group;
+        const int gm = min(G2_GM, ntm - g * G2_GM);   // the last group may hold fewer M-panels
+        tn = r / gm; tm = g * G2_GM + (r - tn * gm);
+    }
     const int m0 = tm * G2_BM, n0 = tn * G2_BN;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int wm = w >> 2, wn = w & 3;
