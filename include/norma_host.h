@@ -50,6 +50,13 @@ void nm_tensors_free(nm_tensors *t);
 nm_model *nm_definition_blocking_try_to_model(const nm_definition *d, const nh_config *cfg, const nh_tokens *tk,
                                               const int32_t *suppress, int n_suppress, const float *mel_filters,
                                               int n_mel, const nm_tensors *tensors, char *err, int err_len);
+/* The same from a local directory with config.json, tokenizer.json, model.safetensors (monolingual.rs:323-373 after
+ * its hf-hub download); installs the byte-level BPE detokeniser so transcribe also produces text (model.rs:147). */
+nm_model *nm_definition_blocking_try_to_model_from_dir(const nm_definition *d, const char *dir, const float *mel_filters,
+                                                       int n_mel, const char *language, int translate, char *err,
+                                                       int err_len);
+/* text of the last nm_model_transcribe call (empty without a tokenizer); returns its length */
+int nm_model_last_text(const nm_model *m, char *buf, int cap);
 void nm_model_free(nm_model *m);
 
 /* Model::transcribe(&mut data, final_chunk).  out_tokens receives the token ids of every emitted segment

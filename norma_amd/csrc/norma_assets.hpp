@@ -1,0 +1,275 @@
+// norma_assets.hpp -- local checkpoint assets for the host layer: config.json -> Config,
+// tokenizer.json -> special-token ids + byte-level BPE detokeniser, model.safetensors -> tensors.
+//
+// Stands in for what the reference does after its hf-hub download (src/models/whisper/monolingual.rs):
+//   :347      serde_json::from_str::<Config>(config.json)
+//   :349      Tokenizer::from_file(tokenizer.json); token_id() lookups :376-384, :419-420 (mod.rs:86-90)
+//   :371-373  VarBuilder::from_mmaped_safetensors(model.safetensors)
+//   model.rs:147  tokenizer.decode(tokens, skip_special_tokens = true)
+// The download itself is out of scope (no network); files are read from a local directory.
+#pragma once
+#include <fcntl.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <map>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace norma {
+namespace assets {
+
+// ---- a small JSON reader (objects, arrays, strings with escapes, numbers, literals) ------------------------
+struct Json {
+    enum Type { Null, Bool, Num, Str, Arr, Obj } type = Null;
+    double num = 0;
+    bool b = false;
+    std::string str;
+    std::vector<Json> arr;
+    std::vector<std::pair<std::string, Json>> obj;  // insertion order kept (safetensors headers are large)
+    const Json *get(const std::string &k) const {
+        for (auto &kv : obj) if (kv.first == k) return &kv.second;
+        return nullptr;
+    }
+};
+
+class JsonParser {
+  public:
+    JsonParser(const char *p, size_t n) : p_(p), e_(p + n) {}
+    bool parse(Json &out) { ws(); bool ok = value(out); ws(); return ok; }
+    std::string error;
+  private:
+    const char *p_, *e_;
+    void ws() { while (p_ < e_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\t' || *p_ == '\r')) p_++; }
+    bool fail(const char *m) { error = m; return false; }
+    static void utf8(std::string &s, unsigned cp) {
+        if (cp < 0x80) s += (char)cp;
+        else if (cp < 0x800) { s += (char)(0xC0 | (cp >> 6)); s += (char)(0x80 | (cp & 0x3F)); }
+        else if (cp < 0x10000) { s += (char)(0xE0 | (cp >> 12)); s += (char)(0x80 | ((cp >> 6) & 0x3F)); s += (char)(0x80 | (cp & 0x3F)); }
+        else { s += (char)(0xF0 | (cp >> 18)); s += (char)(0x80 | ((cp >> 12) & 0x3F)); s += (char)(0x80 | ((cp >> 6) & 0x3F)); s += (char)(0x80 | (cp & 0x3F)); }
+    }
+    bool hex4(unsigned &v) {
+        if (e_ - p_ < 4) return false;
+        v = 0;
+        for (int i = 0; i < 4; i++) {
+            char c = *p_++;
+            v <<= 4;
+            if (c >= '0' && c <= '9') v |= c - '0';
+            else if (c >= 'a' && c <= 'f') v |= c - 'a' + 10;
+            else if (c >= 'A' && c <= 'F') v |= c - 'A' + 10;
+            else return false;
+        }
+        return true;
+    }
+    bool string(std::string &s) {
+        if (p_ >= e_ || *p_ != '"') return fail("expected string");
+        p_++;
+        while (p_ < e_ && *p_ != '"') {
+            if (*p_ == '\\') {
+                if (++p_ >= e_) return fail("bad escape");
+                char c = *p_++;
+                switch (c) {
+                    case 'n': s += '\n'; break; case 't': s += '\t'; break; case 'r': s += '\r'; break;
+                    case 'b': s += '\b'; break; case 'f': s += '\f'; break;
+                    case 'u': {
+                        unsigned cp;
+                        if (!hex4(cp)) return fail("bad \\u");
+                        if (cp >= 0xD800 && cp < 0xDC00 && e_ - p_ >= 6 && p_[0] == '\\' && p_[1] == 'u') {
+                            p_ += 2; unsigned lo;
+                            if (!hex4(lo)) return fail("bad surrogate");
+                            cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00);
+                        }
+                        utf8(s, cp);
+                        break;
+                    }
+                    default: s += c;
+                }
+            } else s += *p_++;
+        }
+        if (p_ >= e_) return fail("unterminated string");
+        p_++;
+        return true;
+    }
+    bool value(Json &v) {
+        if (p_ >= e_) return fail("unexpected end");
+        if (*p_ == '{') {
+            v.type = Json::Obj; p_++; ws();
+            if (p_ < e_ && *p_ == '}') { p_++; return true; }
+            while (true) {
+                std::string k; ws();
+                if (!string(k)) return false;
+                ws();
+                if (p_ >= e_ || *p_ != ':') return fail("expected ':'");
+                p_++; ws();
+                v.obj.emplace_back(std::move(k), Json());
+                if (!value(v.obj.back().second)) return false;
+                ws();
+                if (p_ < e_ && *p_ == ',') { p_++; continue; }
+                if (p_ < e_ && *p_ == '}') { p_++; return true; }
+                return fail("expected ',' or '}'");
+            }
+        }
+        if (*p_ == '[') {
+            v.type = Json::Arr; p_++; ws();
+            if (p_ < e_ && *p_ == ']') { p_++; return true; }
+            while (true) {
+                v.arr.emplace_back();
+                ws();
+                if (!value(v.arr.back())) return false;
+                ws();
+                if (p_ < e_ && *p_ == ',') { p_++; continue; }
+                if (p_ < e_ && *p_ == ']') { p_++; return true; }
+                return fail("expected ',' or ']'");
+            }
+        }
+        if (*p_ == '"') { v.type = Json::Str; return string(v.str); }
+        if (!strncmp(p_, "true", 4) && e_ - p_ >= 4) { v.type = Json::Bool; v.b = true; p_ += 4; return true; }
+        if (!strncmp(p_, "false", 5) && e_ - p_ >= 5) { v.type = Json::Bool; v.b = false; p_ += 5; return true; }
+        if (!strncmp(p_, "null", 4) && e_ - p_ >= 4) { v.type = Json::Null; p_ += 4; return true; }
+        char *end = nullptr;
+        v.num = strtod(p_, &end);
+        if (end == p_) return fail("bad value");
+        v.type = Json::Num; p_ = end;
+        return true;
+    }
+};
+
+// ---- read-only mmap -------------------------------------------------------------------------------------------
+class MappedFile {
+  public:
+    ~MappedFile() { if (p_) munmap(const_cast<char *>(p_), n_); }
+    bool open(const std::string &path, std::string &err) {
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) { err = "cannot open " + path; return false; }
+        struct stat st;
+        if (fstat(fd, &st) != 0 || st.st_size == 0) { ::close(fd); err = "cannot stat " + path; return false; }
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) { err = "cannot mmap " + path; return false; }
+        p_ = (const char *)m; n_ = (size_t)st.st_size;
+        return true;
+    }
+    const char *data() const { return p_; }
+    size_t size() const { return n_; }
+  private:
+    const char *p_ = nullptr; size_t n_ = 0;
+};
+
+// ---- safetensors: u64 header length, JSON header {name: {dtype, shape, data_offsets}}, raw little-endian data ---
+struct StTensor { std::string name; std::string dtype; std::vector<int64_t> shape; const void *data; size_t bytes; };
+
+class SafeTensors {
+  public:
+    bool open(const std::string &path, std::string &err) {
+        if (!f_.open(path, err)) return false;
+        if (f_.size() < 8) { err = "safetensors: file too small"; return false; }
+        uint64_t hl; memcpy(&hl, f_.data(), 8);
+        if (8 + hl > f_.size()) { err = "safetensors: bad header length"; return false; }
+        Json h; JsonParser jp(f_.data() + 8, (size_t)hl);
+        if (!jp.parse(h) || h.type != Json::Obj) { err = "safetensors: " + jp.error; return false; }
+        const char *base = f_.data() + 8 + hl;
+        const size_t avail = f_.size() - 8 - (size_t)hl;
+        for (auto &kv : h.obj) {
+            if (kv.first == "__metadata__") continue;
+            const Json *dt = kv.second.get("dtype"), *sh = kv.second.get("shape"), *off = kv.second.get("data_offsets");
+            if (!dt || !sh || !off || off->arr.size() != 2) { err = "safetensors: malformed entry " + kv.first; return false; }
+            StTensor t; t.name = kv.first; t.dtype = dt->str;
+            for (auto &d : sh->arr) t.shape.push_back((int64_t)d.num);
+            size_t b = (size_t)off->arr[0].num, e = (size_t)off->arr[1].num;
+            if (e < b || e > avail) { err = "safetensors: offsets out of range for " + kv.first; return false; }
+            t.data = base + b; t.bytes = e - b;
+            tensors.push_back(std::move(t));
+        }
+        return true;
+    }
+    std::vector<StTensor> tensors;
+  private:
+    MappedFile f_;
+};
+
+// ---- config.json: the fields candle's Config reads -------------------------------------------
+struct ConfigJson {
+    int num_mel_bins = 0, max_source_positions = 0, d_model = 0, encoder_attention_heads = 0, encoder_layers = 0,
+        vocab_size = 0, max_target_positions = 0, decoder_attention_heads = 0, decoder_layers = 0;
+    std::vector<int32_t> suppress_tokens;
+    bool load(const std::string &path, std::string &err) {
+        MappedFile f;
+        if (!f.open(path, err)) return false;
+        Json j; JsonParser jp(f.data(), f.size());
+        if (!jp.parse(j) || j.type != Json::Obj) { err = "config.json: " + jp.error; return false; }
+        auto geti = [&](const char *k, int &dst) { const Json *v = j.get(k); if (!v || v->type != Json::Num) { err = std::string("config.json: missing ") + k; return false; } dst = (int)v->num; return true; };
+        if (!geti("num_mel_bins", num_mel_bins) || !geti("max_source_positions", max_source_positions) || !geti("d_model", d_model) ||
+            !geti("encoder_attention_heads", encoder_attention_heads) || !geti("encoder_layers", encoder_layers) ||
+            !geti("vocab_size", vocab_size) || !geti("max_target_positions", max_target_positions) ||
+            !geti("decoder_attention_heads", decoder_attention_heads) || !geti("decoder_layers", decoder_layers)) return false;
+        if (const Json *s = j.get("suppress_tokens")) for (auto &t : s->arr) suppress_tokens.push_back((int32_t)t.num);
+        return true;
+    }
+};
+
+// ---- tokenizer.json: token -> id (model.vocab + added_tokens) and the byte-level BPE decoder -------------------
+class TokenizerJson {
+  public:
+    bool load(const std::string &path, std::string &err) {
+        MappedFile f;
+        if (!f.open(path, err)) return false;
+        Json j; JsonParser jp(f.data(), f.size());
+        if (!jp.parse(j) || j.type != Json::Obj) { err = "tokenizer.json: " + jp.error; return false; }
+        if (const Json *m = j.get("model"))
+            if (const Json *v = m->get("vocab"))
+                for (auto &kv : v->obj) put(kv.first, (int)kv.second.num, false);
+        if (const Json *a = j.get("added_tokens"))
+            for (auto &t : a->arr) {
+                const Json *id = t.get("id"), *c = t.get("content"), *sp = t.get("special");
+                if (id && c) put(c->str, (int)id->num, sp ? sp->b : true);
+            }
+        if (id_to_tok_.empty()) { err = "tokenizer.json: no vocabulary"; return false; }
+        // GPT-2 bytes_to_unicode: printable bytes map to themselves, the rest to U+0100 + n
+        int n = 0;
+        for (int b = 0; b < 256; b++) {
+            bool keep = (b >= 33 && b <= 126) || (b >= 161 && b <= 172) || (b >= 174 && b <= 255);
+            uni_to_byte_[keep ? (unsigned)b : 256u + (unsigned)n++] = (unsigned char)b;
+        }
+        return true;
+    }
+    // Tokenizer::token_to_id (whisper/mod.rs:86-90); -1 = Error::TokenId
+    int token_to_id(const std::string &tok) const { auto it = tok_to_id_.find(tok); return it == tok_to_id_.end() ? -1 : it->second; }
+    // Tokenizer::decode(ids, skip_special_tokens = true) for a ByteLevel BPE model
+    std::string decode(const uint32_t *ids, size_t n) const {
+        std::string bytes;
+        for (size_t i = 0; i < n; i++) {
+            if (ids[i] >= id_to_tok_.size() || special_[ids[i]]) continue;
+            const std::string &t = id_to_tok_[ids[i]];
+            for (size_t p = 0; p < t.size();) {  // UTF-8 code points -> original bytes
+                unsigned c = (unsigned char)t[p], cp; int len;
+                if (c < 0x80) { cp = c; len = 1; } else if ((c >> 5) == 6) { cp = c & 0x1F; len = 2; }
+                else if ((c >> 4) == 14) { cp = c & 0x0F; len = 3; } else { cp = c & 0x07; len = 4; }
+                for (int k = 1; k < len && p + k < t.size(); k++) cp = (cp << 6) | ((unsigned char)t[p + k] & 0x3F);
+                p += len;
+                auto it = uni_to_byte_.find(cp);
+                if (it != uni_to_byte_.end()) bytes += (char)it->second;
+            }
+        }
+        return bytes;
+    }
+    size_t size() const { return id_to_tok_.size(); }
+  private:
+    void put(const std::string &tok, int id, bool special) {
+        if (id < 0) return;
+        if ((size_t)id >= id_to_tok_.size()) { id_to_tok_.resize(id + 1); special_.resize(id + 1, false); }
+        id_to_tok_[id] = tok; special_[id] = special; tok_to_id_[tok] = id;
+    }
+    std::vector<std::string> id_to_tok_;
+    std::vector<bool> special_;
+    std::unordered_map<std::string, int> tok_to_id_;
+    std::unordered_map<unsigned, unsigned char> uni_to_byte_;
+};
+
+}  // namespace assets
+}  // namespace norma

@@ -9,7 +9,7 @@ using namespace norma;
 using namespace norma::whisper;
 
 struct nm_definition { Definition def; };
-struct nm_model { Model *m; };
+struct nm_model { Model *m; std::string last_text; };
 struct nm_tensors { std::vector<TensorView> v; };
 
 static void put_err(char *err, int n, const std::string &s) {
@@ -45,7 +45,23 @@ nm_model *nm_definition_blocking_try_to_model(const nm_definition *d, const nh_c
     std::vector<int32_t> sup(suppress, suppress + (n_suppress > 0 ? n_suppress : 0));
     Error e = d->def.blocking_try_to_model(*cfg, *tk, sup, mel_filters, n_mel, tensors->v, &m);
     if (e) { put_err(err, err_len, e.message); return nullptr; }
-    return new nm_model{m};
+    return new nm_model{m, std::string()};
+}
+
+nm_model *nm_definition_blocking_try_to_model_from_dir(const nm_definition *d, const char *dir, const float *mel_filters,
+                                                       int n_mel, const char *language, int translate, char *err,
+                                                       int err_len) {
+    Model *m = nullptr;
+    Error e = d->def.blocking_try_to_model_from_dir(dir, mel_filters, n_mel, &m, language ? language : "<|en|>", translate != 0);
+    if (e) { put_err(err, err_len, e.message); return nullptr; }
+    return new nm_model{m, std::string()};
+}
+
+int nm_model_last_text(const nm_model *m, char *buf, int cap) {
+    if (!buf || cap <= 0) return (int)m->last_text.size();
+    strncpy(buf, m->last_text.c_str(), (size_t)cap - 1);
+    buf[cap - 1] = 0;
+    return (int)m->last_text.size();
 }
 void nm_model_free(nm_model *m) { if (m) { delete m->m; delete m; } }
 
@@ -53,7 +69,8 @@ int nm_model_transcribe(nm_model *m, const float *data, size_t n, int final_chun
                         int *n_out, size_t *buffered, char *err, int err_len) {
     std::vector<float> v(data, data + n);
     std::vector<Segment> segs;
-    Error e = m->m->transcribe(v, final_chunk != 0, segs);
+    m->last_text.clear();
+    Error e = m->m->transcribe(v, final_chunk != 0, segs, &m->last_text);
     if (buffered) *buffered = m->m->buffered_samples();
     if (e) { put_err(err, err_len, e.message); return 1; }
     int w = 0;

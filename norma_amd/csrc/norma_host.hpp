@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "../../include/norma_hip.h"
+#include "norma_assets.hpp"
 
 namespace norma {
 
@@ -191,6 +192,7 @@ class Model {
         return Error{};
     }
     const DecodingResult &last_result() const { return last_; }
+    bool has_detokenizer() const { return (bool)detok_; }
     bool last_needed_fallback() const { return needs_fallback_; }
 
   private:
@@ -241,6 +243,45 @@ class Definition {
         if (nh_set_mel_filters(ctx, mel_filters, n_mel)) return fail();
         if (nh_set_tokens(ctx, &tk, suppress.data(), (int)suppress.size())) return fail();
         *out = new Model(ctx, cfg, tk);
+        return Error{};
+    }
+
+    // The same from a local checkpoint directory holding config.json, tokenizer.json and model.safetensors
+    // (what monolingual.rs:323-373 reads after the hf-hub download).  `language` is the `<|xx|>` token of
+    // ModelType::language() (monolingual.rs:85-97, :384); translate selects <|translate|> (multilingual.rs:383-386).
+    Error blocking_try_to_model_from_dir(const std::string &dir, const float *mel_filters, int n_mel, Model **out,
+                                         const std::string &language = "<|en|>", bool translate = false) const {
+        std::string err;
+        assets::ConfigJson cj;
+        if (!cj.load(dir + "/config.json", err)) return Error{Error::Backend, err};
+        auto tok = std::make_shared<assets::TokenizerJson>();
+        if (!tok->load(dir + "/tokenizer.json", err)) return Error{Error::Backend, err};
+        auto id = [&](const char *t, int &dst) { dst = tok->token_to_id(t); return dst >= 0; };
+        nh_tokens tk{};
+        // candle constants m::SOT_TOKEN, EOT_TOKEN, TRANSCRIBE_TOKEN, TRANSLATE_TOKEN, NO_TIMESTAMPS_TOKEN, NO_SPEECH_TOKENS
+        if (!id("<|startoftranscript|>", tk.sot)) return Error{Error::TokenId, "Failed to get token ID for: <|startoftranscript|>"};
+        if (!id("<|endoftext|>", tk.eot)) return Error{Error::TokenId, "Failed to get token ID for: <|endoftext|>"};
+        if (!id(translate ? "<|translate|>" : "<|transcribe|>", tk.task)) return Error{Error::TokenId, "Failed to get token ID for the task token"};
+        if (!id("<|nocaptions|>", tk.no_speech) && !id("<|nospeech|>", tk.no_speech)) return Error{Error::TokenId, "Failed to get token ID for: <|nocaptions|> nor <|nospeech|>"};
+        if (!id("<|notimestamps|>", tk.no_timestamps)) return Error{Error::TokenId, "Failed to get token ID for: <|notimestamps|>"};
+        if (!id(language.c_str(), tk.lang)) return Error{Error::TokenId, "Failed to get token ID for: " + language};
+        if (!id("<|0.00|>", tk.zero_sec)) return Error{Error::TokenId, "Failed to get token ID for: <|0.00|>"};
+        if (!id("<|1.00|>", tk.one_sec)) return Error{Error::TokenId, "Failed to get token ID for: <|1.00|>"};
+        assets::SafeTensors st;
+        if (!st.open(dir + "/model.safetensors", err)) return Error{Error::Backend, err};
+        std::vector<TensorView> tv;
+        for (const auto &t : st.tensors) {
+            int dt;
+            if (t.dtype == "F16") dt = NH_DTYPE_F16;
+            else if (t.dtype == "F32") dt = NH_DTYPE_F32;
+            else return Error{Error::Backend, "model.safetensors: unsupported dtype " + t.dtype + " for " + t.name};
+            tv.push_back(TensorView{t.name, dt, t.shape, t.data});
+        }
+        nh_config cfg{cj.num_mel_bins, cj.max_source_positions, cj.d_model, cj.encoder_attention_heads, cj.encoder_layers,
+                      cj.vocab_size, cj.max_target_positions, cj.decoder_attention_heads, cj.decoder_layers};
+        Error e = blocking_try_to_model(cfg, tk, cj.suppress_tokens, mel_filters, n_mel, tv, out);
+        if (e) return e;
+        (*out)->set_detokenizer([tok](const uint32_t *ids, size_t n) { return tok->decode(ids, n); });  // model.rs:147
         return Error{};
     }
 

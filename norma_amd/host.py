@@ -83,6 +83,10 @@ def _lib():
         L.nm_definition_blocking_try_to_model.argtypes = [vp, C.POINTER(hip.NhConfig), C.POINTER(hip.NhTokens),
                                                           C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_float), C.c_int,
                                                           vp, C.c_char_p, C.c_int]
+        L.nm_definition_blocking_try_to_model_from_dir.restype = vp
+        L.nm_definition_blocking_try_to_model_from_dir.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_char_p,
+                                                                   C.c_int, C.c_char_p, C.c_int]
+        L.nm_model_last_text.argtypes = [vp, C.c_char_p, C.c_int]
         L.nm_model_free.argtypes = [vp]
         L.nm_model_transcribe.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_int32), C.c_int,
                                           C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.c_char_p, C.c_int]
@@ -134,6 +138,13 @@ class Model:
                 cur.append(t)
         return segs
 
+    def last_text(self) -> str:
+        """Concatenated text of the last transcribe call (needs a model loaded with a tokenizer)."""
+        n = _lib().nm_model_last_text(self._h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        _lib().nm_model_last_text(self._h, buf, n + 1)
+        return buf.value.decode("utf-8", errors="replace")
+
     def last_result(self) -> dict:
         a, n, f, k = C.c_double(0), C.c_double(0), C.c_int(0), C.c_int(0)
         _lib().nm_model_last_result(self._h, C.byref(a), C.byref(n), C.byref(f), C.byref(k))
@@ -169,6 +180,22 @@ class Definition:
     @property
     def data_buffer_size(self) -> int:
         return int(_lib().nm_definition_data_buffer_size(self._h))
+
+    def blocking_try_to_model_from_dir(self, path: str, language: str = "<|en|>", translate: bool = False,
+                                       ctx_len: int = 448) -> Model:
+        """Load config.json / tokenizer.json / model.safetensors from a local directory (the files the reference
+        fetches through hf-hub, monolingual.rs:323-345)."""
+        import json
+        import os
+        with open(os.path.join(path, "config.json")) as f:
+            n_mel = json.load(f)["num_mel_bins"]
+        filt = np.ascontiguousarray(assets_io.mel_filters(n_mel), dtype=np.float32)
+        err = C.create_string_buffer(512)
+        h = _lib().nm_definition_blocking_try_to_model_from_dir(self._h, path.encode(), filt.ctypes.data_as(C.POINTER(C.c_float)),
+                                                                filt.shape[0], language.encode(), int(translate), err, 512)
+        if not h:
+            raise WhisperError(err.value.decode())
+        return Model(C.c_void_p(h), ctx_len)
 
     def blocking_try_to_model(self, cfg: Config, tokens, lang: int, task: int,
                               weights: Iterable[Tuple[str, np.ndarray]], mel_filters: Optional[np.ndarray] = None) -> Model:

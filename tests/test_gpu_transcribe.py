@@ -85,3 +85,70 @@ def test_no_speech_result_drains_instead_of_spinning_forever():
     assert segs == ref == [] and model.buffered_samples == len(buf) == 0
     assert model.last_result()["no_speech_prob"] > 0.6
     model.close()
+
+
+def _bytes_to_unicode():
+    bs = list(range(33, 127)) + list(range(161, 173)) + list(range(174, 256))
+    cs = bs[:]
+    n = 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b); cs.append(256 + n); n += 1
+    return {b: chr(c) for b, c in zip(bs, cs)}
+
+
+def _write_checkpoint_dir(path, cfg, tk, weights):
+    """config.json + tokenizer.json (byte-level BPE layout with Whisper's added tokens) + model.safetensors, the three
+    files the reference pulls through hf-hub (monolingual.rs:323-345); contents are synthetic."""
+    import json
+    import os
+    from safetensors.numpy import save_file
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump(cfg.to_dict(), f)
+    b2u = _bytes_to_unicode()
+    words = {}
+    for i in range(tk.eot):                       # ordinary vocabulary: " w<i>" in GPT-2 byte-level spelling
+        words[i] = "".join(b2u[b] for b in f" w{i}".encode())
+    vocab = {v: k for k, v in words.items()}
+    added = [dict(id=tk.eot, content="<|endoftext|>", special=True), dict(id=tk.sot, content="<|startoftranscript|>", special=True),
+             dict(id=tk.en, content="<|en|>", special=True), dict(id=tk.translate, content="<|translate|>", special=True),
+             dict(id=tk.transcribe, content="<|transcribe|>", special=True), dict(id=tk.no_speech, content="<|nocaptions|>", special=True),
+             dict(id=tk.no_timestamps, content="<|notimestamps|>", special=True)]
+    for i in range(1501):
+        added.append(dict(id=tk.zero_sec + i, content=f"<|{i * 0.02:.2f}|>", special=True))
+    with open(os.path.join(path, "tokenizer.json"), "w") as f:
+        json.dump(dict(version="1.0", added_tokens=added, model=dict(type="BPE", vocab=vocab, merges=[])), f)
+    tensors = {n: a.astype(np.float16) for n, a in weights}
+    tensors["proj_out.weight"] = tensors["model.decoder.embed_tokens.weight"]        # present in HF files, not read by candle
+    tensors["model.encoder.embed_positions.weight"] = np.zeros((1500, cfg.d_model), np.float16)
+    save_file(tensors, os.path.join(path, "model.safetensors"))
+    return words
+
+
+def test_local_checkpoint_directory_loads_and_yields_text(tmp_path):
+    """§8(f)-1: safetensors / config.json / tokenizer.json read by the C++ host layer; special-token ids resolved by
+    name as the reference does (mod.rs:86-90), text through the byte-level BPE decoder (model.rs:147)."""
+    name = "test-d128"
+    cfg = config.preset(name)
+    tk = common.tokens_for(name)
+    script = common.transcript_script(tk, n_segments=3, words_per_segment=4)
+    over = common.scripted_overrides(cfg, tk, script)
+    words = _write_checkpoint_dir(str(tmp_path), cfg, tk, synth.synth_weights(cfg, 0, over))
+    d = host.Definition(host.ModelType.TinyEn, host.SelectedDevice.Rocm(0))
+    model = d.blocking_try_to_model_from_dir(str(tmp_path))
+    pcm = synth.synth_pcm(0)
+    segs = model.transcribe(pcm, final_chunk=True)
+    # same tokens as the model built by injecting the tensors directly
+    ref_model = d.blocking_try_to_model(cfg, tk, tk.en, tk.transcribe,
+                                        ((n, a.astype(np.float16)) for n, a in synth.synth_weights(cfg, 0, over)))
+    assert segs == ref_model.transcribe(pcm, final_chunk=True) and len(segs) == 3
+    expect = "".join("".join(f" w{t}" for t in s) for s in segs)
+    assert model.last_text() == expect
+    model.close(); ref_model.close()
+    # a checkpoint whose tokenizer lacks a required token fails with the reference's TokenId error
+    import json, os
+    tj = json.load(open(os.path.join(tmp_path, "tokenizer.json")))
+    tj["added_tokens"] = [t for t in tj["added_tokens"] if t["content"] != "<|notimestamps|>"]
+    json.dump(tj, open(os.path.join(tmp_path, "tokenizer.json"), "w"))
+    with pytest.raises(host.WhisperError, match="Failed to get token ID for: <|notimestamps|>".replace("|", r"\|")):
+        d.blocking_try_to_model_from_dir(str(tmp_path))
