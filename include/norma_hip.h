@@ -21,9 +21,10 @@
  *   nh_encode                     Type::encoder_forward (model.rs:168, :455-464)
  *   nh_decode_greedy              Model::decode at t = 0 (model.rs:279-389) including the logit
  *                                 rules (model.rs:212-277), batched, on device
- *   nh_encoder_output, nh_decoder_forward, nh_final_linear, nh_decode_probs
+ *   nh_encoder_output, nh_decoder_forward, nh_final_linear, nh_apply_rules
  *                                 fine-grained views of the same state for layer-level parity:
  *                                 Type::decoder_forward / decoder_final_linear (model.rs:466-483)
+ *   nh_detect_language            Model::detect_language (model.rs:194-210)
  *   nh_reset                      Type::reset_kv_cache (model.rs:485-490)
  */
 #ifndef NORMA_HIP_H
@@ -113,6 +114,13 @@ int nh_encode(nh_ctx *ctx);
 /* Greedy decode of all `batch` sequences.  out_tokens: host i32 [batch][max_target_positions],
  * results: [batch].  max_new_tokens <= 0: reference behaviour (cap at max_target_positions - 1). */
 int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *results, int max_new_tokens);
+/* Model::detect_language (model.rs:194-210) for every clip of the batch: one decoder step on [sot], softmax over the
+ * n language-token logits (lang_tokens in `Language::iter()` order, multilingual.rs:395-398), first maximum.
+ * out_lang: host i32 [batch]; out_probs: host f32 [batch][n] or NULL.  The detected tokens become the per-sequence
+ * language tokens of the next nh_decode_greedy (LanguageState::set_language_token). */
+int nh_detect_language(nh_ctx *ctx, const int32_t *lang_tokens, int n, int32_t *out_lang, float *out_probs);
+/* Per-sequence language tokens for the next decode (host i32 [batch]); NULL: back to nh_tokens.lang for all. */
+int nh_set_languages(nh_ctx *ctx, const int32_t *langs);
 /* Device-resident log-mel -> encoder -> decode without intermediate host syncs (bench path). */
 int nh_transcribe_batch(nh_ctx *ctx, const float *pcm_dev, const int32_t *n_samples, int64_t stride,
                         int batch, int32_t *out_tokens, nh_decode_result *results, int max_new_tokens);

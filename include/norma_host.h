@@ -55,6 +55,11 @@ nm_model *nm_definition_blocking_try_to_model(const nm_definition *d, const nh_c
 nm_model *nm_definition_blocking_try_to_model_from_dir(const nm_definition *d, const char *dir, const float *mel_filters,
                                                        int n_mel, const char *language, int translate, char *err,
                                                        int err_len);
+/* multilingual models: LanguageState::Detect (model.rs:393-440).  lang_tokens in Language::iter() order
+ * (languages.rs:7-107); the language is inferred on the first slice and cleared on final_chunk.
+ * (nm_definition_blocking_try_to_model_from_dir enables it itself when `language` is NULL or "".) */
+void nm_model_enable_language_detection(nm_model *m, const int32_t *lang_tokens, int n);
+int nm_model_language_token(const nm_model *m); /* current language token, -1 = not detected yet */
 /* text of the last nm_model_transcribe call (empty without a tokenizer); returns its length */
 int nm_model_last_text(const nm_model *m, char *buf, int cap);
 void nm_model_free(nm_model *m);

@@ -682,6 +682,49 @@ void launch_logit_step(const float *logits, int V, DecodeState s, RuleTokens tk,
                        prompt_len, mode, partials, tickets, pos_ptr);
 }
 
+// Model::detect_language (model.rs:194-210) on the position-0 logits of a [sot] prompt: softmax over the language
+// tokens and the FIRST maximum (the reference sorts descending with a stable sort).  One wave per sequence.
+__global__ __launch_bounds__(64) void lang_detect_kernel(const float *__restrict__ logits, int ldl,
+                                                         const int32_t *__restrict__ lang_tokens, int n,
+                                                         float *__restrict__ probs_out, int32_t *__restrict__ lang_out) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float *lg = logits + (long)b * ldl;
+    float v[4]; int idx[4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        idx[u] = lane + 64 * u;
+        v[u] = idx[u] < n ? lg[lang_tokens[idx[u] < n ? idx[u] : 0]] : -INFINITY;
+        mx = fmaxf(mx, v[u]);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float se = 0.f, e[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { e[u] = idx[u] < n ? expf(v[u] - mx) : 0.f; se += e[u]; }
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o);
+    int bk = INT_MIN, bi = 0x7fffffff;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (idx[u] < n) {
+            float p = e[u] / se;
+            if (probs_out) probs_out[(long)b * n + idx[u]] = p;
+            int key = total_key(p);
+            if (key > bk || (key == bk && idx[u] < bi)) { bk = key; bi = idx[u]; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        int k2 = __shfl_xor(bk, o), i2 = __shfl_xor(bi, o);
+        if (k2 > bk || (k2 == bk && i2 < bi)) { bk = k2; bi = i2; }
+    }
+    if (lane == 0) lang_out[b] = lang_tokens[bi];
+}
+
+void launch_lang_detect(const float *logits, int V, const int32_t *lang_tokens, int n, float *probs_out, int32_t *lang_out,
+                        int B, hipStream_t st) {
+    int ldl = (V + 63) & ~63;
+    hipLaunchKernelGGL(lang_detect_kernel, dim3(B), dim3(64), 0, st, logits, ldl, lang_tokens, n, probs_out, lang_out);
+}
+
 __global__ __launch_bounds__(1024) void rules_only_kernel(const float *__restrict__ probs_in, float *masked_out,
                                                           int32_t *argmax_out, const int32_t *tokens, int n,
                                                           int last_ts, const uint8_t *sup, RuleTokens tk, int V) {

@@ -74,6 +74,9 @@ struct nh_ctx {
     int32_t *d_pos = nullptr;  // device-side decode position (hipGraph replays read it)
     hipGraphExec_t step_graph = nullptr;
     int graph_key[5] = {-1, -1, -1, -1, -1};
+    std::vector<int32_t> seq_lang;  // per-sequence language tokens (LanguageState::Detect), empty = tk.lang for all
+    int32_t *d_lang_tokens = nullptr, *d_lang_out = nullptr;
+    float *d_lang_probs = nullptr;
     RuleTokens tk{};
     bool have_tokens = false;
     int VP = 0;
@@ -264,7 +267,7 @@ extern "C" int nh_create(int device_ordinal, const nh_config *cfg, int max_batch
     DA(dxn, half_t, (long)B * d); DA(dq, half_t, (long)B * d); DA(datt, half_t, (long)B * d); DA(dhid, half_t, (long)B * 4 * d);
     DA(ds.tokens, int32_t, (long)B * ctxlen); DA(ds.n_tokens, int32_t, B); DA(ds.done, int32_t, B);
     DA(ds.have_last, int32_t, B); DA(ds.last_ts, int32_t, B); DA(ds.sum_logprob, double, B); DA(ds.no_speech, double, B);
-    DA(ds.n_active, int32_t, 1); DA(suppress, uint8_t, V); DA(lpart, float, (long)B * 64); DA(ltick, unsigned, B); DA(d_pos, int32_t, 4); DA(sk_slabs, float, (long)SKINNY_MAX_TILES * 8 * 64 * 16); DA(sk_tickets, unsigned, SKINNY_MAX_TILES);
+    DA(ds.n_active, int32_t, 1); DA(suppress, uint8_t, V); DA(lpart, float, (long)B * 64); DA(ltick, unsigned, B); DA(d_pos, int32_t, 4); DA(d_lang_tokens, int32_t, 256); DA(d_lang_out, int32_t, B); DA(d_lang_probs, float, (long)B * 256); DA(sk_slabs, float, (long)SKINNY_MAX_TILES * 8 * 64 * 16); DA(sk_tickets, unsigned, SKINNY_MAX_TILES);
 #undef DA
     if (!ok) { ctx->err = "hipMalloc failed while sizing the context (out of device memory?)"; return bail(NH_ERR_NOMEM); }
     ctx->ds.suppress = ctx->suppress;
@@ -467,6 +470,7 @@ static int prepare_batch(nh_ctx *ctx, const int32_t *n_samples, int batch) {
     }
     ctx->cur_batch = batch; ctx->frames = (int)fr; ctx->S = (int)((fr + 2 - 3) / 2 + 1);
     ctx->have_mel = false; ctx->have_enc = false;
+    ctx->seq_lang.clear();
     if (ctx->frames != ctx->last_frames) {  // the zero rows framing each clip move with the frame count
         HIPCHK(hipMemsetAsync(ctx->mel_img, 0, sizeof(half_t) * (size_t)ctx->B * (NH_N_FRAMES + 2) * NH_MELP, ctx->st));
         HIPCHK(hipMemsetAsync(ctx->h1, 0, sizeof(half_t) * (size_t)ctx->B * (NH_N_FRAMES + 2) * ctx->c.d_model, ctx->st));
@@ -660,13 +664,16 @@ extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_resu
     hipSetDevice(ctx->dev);
     const int B = ctx->cur_batch, C = ctx->c.max_target_positions, cap = C - 1, V = ctx->c.vocab_size;
     // model.rs:285-289: prompt = [sot, lang?, task]
-    std::vector<int32_t> prompt;
-    prompt.push_back(ctx->tk.sot);
-    if (ctx->tk.lang >= 0) prompt.push_back(ctx->tk.lang);
-    prompt.push_back(ctx->tk.task);
-    const int P = (int)prompt.size();  // 2 or 3, so position 0 is never a generation step
+    const bool per_seq = (int)ctx->seq_lang.size() == B;
+    const int P = (per_seq || ctx->tk.lang >= 0) ? 3 : 2;  // 2 or 3, so position 0 is never a generation step
     std::vector<int32_t> toks((size_t)B * C, 0), nt(B, P);
-    for (int b = 0; b < B; b++) for (int i = 0; i < P; i++) toks[(size_t)b * C + i] = prompt[i];
+    for (int b = 0; b < B; b++) {
+        int32_t *t = toks.data() + (size_t)b * C;
+        int i = 0;
+        t[i++] = ctx->tk.sot;
+        if (P == 3) t[i++] = per_seq ? ctx->seq_lang[b] : ctx->tk.lang;
+        t[i++] = ctx->tk.task;
+    }
     HIPCHK(hipStreamWaitEvent(ctx->sd, ctx->enc_done, 0));  // the encoder and cross K/V ran on the other stream
     HIPCHK(hipMemcpyAsync(ctx->ds.tokens, toks.data(), toks.size() * 4, hipMemcpyHostToDevice, ctx->sd));
     HIPCHK(hipMemcpyAsync(ctx->ds.n_tokens, nt.data(), B * 4, hipMemcpyHostToDevice, ctx->sd));
@@ -753,6 +760,42 @@ extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_resu
         for (int i = n; i < C; i++) out_tokens[(size_t)b * C + i] = 0;
     }
     ctx->tm.decode_steps = steps;
+    return NH_OK;
+}
+
+extern "C" int nh_set_languages(nh_ctx *ctx, const int32_t *langs) {
+    if (!ctx) return NH_ERR_INVALID;
+    ctx->seq_lang.clear();
+    if (langs) {
+        for (int b = 0; b < ctx->cur_batch; b++) {
+            if (langs[b] < 0 || langs[b] >= ctx->c.vocab_size) { ctx->seq_lang.clear(); return ctx->fail(NH_ERR_INVALID, "nh_set_languages: token id outside the vocabulary"); }
+            ctx->seq_lang.push_back(langs[b]);
+        }
+    }
+    return NH_OK;
+}
+
+extern "C" int nh_detect_language(nh_ctx *ctx, const int32_t *lang_tokens, int n, int32_t *out_lang, float *out_probs) {
+    if (!ctx || !lang_tokens || !out_lang || n < 1 || n > 256) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_detect_language: bad arguments (1 <= n <= 256)") : NH_ERR_INVALID;
+    if (!ctx->have_enc) return ctx->fail(NH_ERR_STATE, "nh_detect_language: call nh_encode first");
+    if (!ctx->have_tokens) return ctx->fail(NH_ERR_STATE, "nh_detect_language: call nh_set_tokens first");
+    hipSetDevice(ctx->dev);
+    const int B = ctx->cur_batch, C = ctx->c.max_target_positions, V = ctx->c.vocab_size;
+    for (int i = 0; i < n; i++) if (lang_tokens[i] < 0 || lang_tokens[i] >= V) return ctx->fail(NH_ERR_INVALID, "nh_detect_language: token id outside the vocabulary");
+    std::vector<int32_t> toks((size_t)B * C, 0);
+    for (int b = 0; b < B; b++) toks[(size_t)b * C] = ctx->tk.sot;  // tokens = [[sot]], model.rs:195
+    HIPCHK(hipStreamWaitEvent(ctx->sd, ctx->enc_done, 0));
+    HIPCHK(hipMemcpyAsync(ctx->ds.tokens, toks.data(), toks.size() * 4, hipMemcpyHostToDevice, ctx->sd));
+    HIPCHK(hipMemcpyAsync(ctx->d_lang_tokens, lang_tokens, n * 4, hipMemcpyHostToDevice, ctx->sd));
+    HIPCHK(hipStreamSynchronize(ctx->sd));
+    decoder_step(ctx, 0);
+    logits_from_dxn(ctx, B);
+    launch_lang_detect(ctx->logits, V, ctx->d_lang_tokens, n, out_probs ? ctx->d_lang_probs : nullptr, ctx->d_lang_out, B, ctx->sd);
+    HIPCHK(hipMemcpyAsync(out_lang, ctx->d_lang_out, B * 4, hipMemcpyDeviceToHost, ctx->sd));
+    if (out_probs) HIPCHK(hipMemcpyAsync(out_probs, ctx->d_lang_probs, (size_t)B * n * 4, hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipStreamSynchronize(ctx->sd));
+    HIPCHK(hipGetLastError());
+    ctx->seq_lang.assign(out_lang, out_lang + B);
     return NH_OK;
 }
 

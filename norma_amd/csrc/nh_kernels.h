@@ -118,6 +118,9 @@ struct RuleTokens { int sot, eot, lang, task, no_speech, no_timestamps, zero_sec
 void launch_logit_step(const float *logits, int V, DecodeState s, RuleTokens tk, int B, int ctx, int cap,
                        int max_new, int prompt_len, int mode, float *partials, unsigned *tickets, int32_t *pos_ptr,
                        hipStream_t st);
+// detect_language: logits [B][ldl] at prompt position 0 -> per-sequence language token (first maximum), optional probs [B][n]
+void launch_lang_detect(const float *logits, int V, const int32_t *lang_tokens, int n, float *probs_out, int32_t *lang_out,
+                        int B, hipStream_t st);
 // parity helper: apply rules to one already soft-maxed probability vector
 void launch_rules_only(const float *probs_in, float *masked_out, int32_t *argmax_out, const int32_t *tokens,
                        int n_tokens, int last_ts, const uint8_t *suppress, RuleTokens tk, int V, hipStream_t st);

@@ -52,10 +52,16 @@ nm_model *nm_definition_blocking_try_to_model_from_dir(const nm_definition *d, c
                                                        int n_mel, const char *language, int translate, char *err,
                                                        int err_len) {
     Model *m = nullptr;
-    Error e = d->def.blocking_try_to_model_from_dir(dir, mel_filters, n_mel, &m, language ? language : "<|en|>", translate != 0);
+    const bool detect = language == nullptr || language[0] == 0;  // multilingual::Definition: infer the language
+    Error e = d->def.blocking_try_to_model_from_dir(dir, mel_filters, n_mel, &m, detect ? "" : language, translate != 0, detect);
     if (e) { put_err(err, err_len, e.message); return nullptr; }
     return new nm_model{m, std::string()};
 }
+
+void nm_model_enable_language_detection(nm_model *m, const int32_t *lang_tokens, int n) {
+    m->m->enable_language_detection(std::vector<int32_t>(lang_tokens, lang_tokens + n));
+}
+int nm_model_language_token(const nm_model *m) { return m->m->language_token(); }
 
 int nm_model_last_text(const nm_model *m, char *buf, int cap) {
     if (!buf || cap <= 0) return (int)m->last_text.size();

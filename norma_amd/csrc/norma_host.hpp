@@ -101,6 +101,16 @@ inline VocabVersion vocab_version(ModelType m) {  // monolingual.rs:99-110
     }
 }
 
+// whisper::Language (languages.rs:7-107): the 99 languages in `Language::iter()` order; token = "<|code|>" (:119-222)
+static const char *const LANGUAGE_CODES[99] = {
+    "en", "zh", "de", "es", "ru", "ko", "fr", "ja", "pt", "tr", "pl", "ca", "nl", "ar", "sv", "it", "id", "hi", "fi", "vi",
+    "he", "uk", "el", "ms", "cs", "ro", "da", "hu", "ta", "no", "th", "ur", "hr", "bg", "lt", "la", "mi", "ml", "cy", "sk",
+    "te", "fa", "lv", "bn", "sr", "az", "sl", "kn", "et", "mk", "br", "eu", "is", "hy", "ne", "mn", "bs", "kk", "sq", "sw",
+    "gl", "mr", "pa", "si", "km", "sn", "yo", "so", "af", "oc", "ka", "be", "tg", "sd", "gu", "am", "yi", "lo", "uz", "fo",
+    "ht", "ps", "tk", "nn", "mt", "sa", "lb", "my", "bo", "tl", "mg", "as", "tt", "haw", "ln", "ha", "ba", "jw", "su"};
+
+enum class Task { Transcribe, Translate };  // multilingual.rs:19-25
+
 struct DecodingResult {  // model.rs:494-499
     std::vector<uint32_t> tokens;
     double avg_logprob = 0, no_speech_prob = 0, compression_ratio = 0;
@@ -118,6 +128,10 @@ class Model {
     ~Model() { if (ctx_) nh_destroy(ctx_); }
 
     void set_detokenizer(std::function<std::string(const uint32_t *, size_t)> f) { detok_ = std::move(f); }
+    // LanguageState::Detect (model.rs:393-440): the language is inferred on the first slice of a transcription and
+    // cleared on final_chunk; `language_tokens` in Language::iter() order (multilingual.rs:395-398)
+    void enable_language_detection(std::vector<int32_t> language_tokens) { detect_ = true; lang_tokens_ = std::move(language_tokens); lang_token_ = -1; }
+    int32_t language_token() const { return detect_ ? lang_token_ : tk_.lang; }
     size_t buffered_samples() const { return buf_.size(); }
 
     // Model::transcribe (model.rs:55-159).  `data` is consumed (swapped/appended into the model's buffer).
@@ -166,6 +180,7 @@ class Model {
             else if (!stop && !drained) drain(slice_len);
         }
         if (final_chunk) {                                            // :153-156
+            if (detect_) lang_token_ = -1;                            // self.lang.clear()
             int rc = nh_reset(ctx_);
             if (rc) return backend_error();
         }
@@ -178,6 +193,11 @@ class Model {
         int32_t ns = (int32_t)n;
         if (nh_logmel(ctx_, pcm, &ns, (int64_t)n, 1)) return backend_error();   // audio::pcm_to_mel + narrow, :74-88
         if (nh_encode(ctx_)) return backend_error();                            // encoder_forward(mel, true), :168
+        if (detect_) {                                                          // :170-173
+            if (lang_token_ < 0) {
+                if (nh_detect_language(ctx_, lang_tokens_.data(), (int)lang_tokens_.size(), &lang_token_, nullptr)) return backend_error();
+            } else if (nh_set_languages(ctx_, &lang_token_)) return backend_error();
+        }
         std::vector<int32_t> toks(cfg_.max_target_positions);
         nh_decode_result r{};
         if (nh_decode_greedy(ctx_, toks.data(), &r, 0)) return backend_error(); // decode(audio_features, 0.0), :176
@@ -205,6 +225,9 @@ class Model {
     std::function<std::string(const uint32_t *, size_t)> detok_;
     DecodingResult last_;
     bool needs_fallback_ = false;
+    bool detect_ = false;
+    std::vector<int32_t> lang_tokens_;
+    int32_t lang_token_ = -1;
 };
 
 // One tensor handed to the loader (HF name, f32 or f16 data) -- stands in for the safetensors mmap of
@@ -250,7 +273,8 @@ class Definition {
     // (what monolingual.rs:323-373 reads after the hf-hub download).  `language` is the `<|xx|>` token of
     // ModelType::language() (monolingual.rs:85-97, :384); translate selects <|translate|> (multilingual.rs:383-386).
     Error blocking_try_to_model_from_dir(const std::string &dir, const float *mel_filters, int n_mel, Model **out,
-                                         const std::string &language = "<|en|>", bool translate = false) const {
+                                         const std::string &language = "<|en|>", bool translate = false,
+                                         bool detect_language = false) const {
         std::string err;
         assets::ConfigJson cj;
         if (!cj.load(dir + "/config.json", err)) return Error{Error::Backend, err};
@@ -264,7 +288,15 @@ class Definition {
         if (!id(translate ? "<|translate|>" : "<|transcribe|>", tk.task)) return Error{Error::TokenId, "Failed to get token ID for the task token"};
         if (!id("<|nocaptions|>", tk.no_speech) && !id("<|nospeech|>", tk.no_speech)) return Error{Error::TokenId, "Failed to get token ID for: <|nocaptions|> nor <|nospeech|>"};
         if (!id("<|notimestamps|>", tk.no_timestamps)) return Error{Error::TokenId, "Failed to get token ID for: <|notimestamps|>"};
-        if (!id(language.c_str(), tk.lang)) return Error{Error::TokenId, "Failed to get token ID for: " + language};
+        std::vector<int32_t> lang_tokens;
+        if (detect_language) {  // multilingual::Definition: LanguageState::Detect (multilingual.rs:395-398, :463-466)
+            tk.lang = -1;
+            for (const char *code : LANGUAGE_CODES) {
+                int t = tok->token_to_id(std::string("<|") + code + "|>");
+                if (t < 0) return Error{Error::TokenId, std::string("Failed to get token ID for: <|") + code + "|>"};
+                lang_tokens.push_back(t);
+            }
+        } else if (!id(language.c_str(), tk.lang)) return Error{Error::TokenId, "Failed to get token ID for: " + language};
         if (!id("<|0.00|>", tk.zero_sec)) return Error{Error::TokenId, "Failed to get token ID for: <|0.00|>"};
         if (!id("<|1.00|>", tk.one_sec)) return Error{Error::TokenId, "Failed to get token ID for: <|1.00|>"};
         assets::SafeTensors st;
@@ -282,6 +314,7 @@ class Definition {
         Error e = blocking_try_to_model(cfg, tk, cj.suppress_tokens, mel_filters, n_mel, tv, out);
         if (e) return e;
         (*out)->set_detokenizer([tok](const uint32_t *ids, size_t n) { return tok->decode(ids, n); });  // model.rs:147
+        if (detect_language) (*out)->enable_language_detection(std::move(lang_tokens));
         return Error{};
     }
 

@@ -87,6 +87,8 @@ def load_library() -> C.CDLL:
     L.nh_encode.argtypes = [vp]
     L.nh_decode_greedy.argtypes = [vp, ip, C.POINTER(NhDecodeResult), C.c_int]
     L.nh_transcribe_batch.argtypes = [vp, vp, ip, C.c_int64, C.c_int, ip, C.POINTER(NhDecodeResult), C.c_int]
+    L.nh_detect_language.argtypes = [vp, ip, C.c_int, ip, fp]
+    L.nh_set_languages.argtypes = [vp, ip]
     L.nh_reset.argtypes = [vp]
     L.nh_synchronize.argtypes = [vp]
     L.nh_get_mel.argtypes = [vp, C.c_int, fp]
@@ -238,6 +240,21 @@ class HipWhisper:
                                              max_new_tokens))
         self.batch = B
         return self._results(toks, res)
+
+    def detect_language(self, lang_tokens: Sequence[int], want_probs: bool = True):
+        """Model::detect_language for every clip; the result also becomes the decode prompt's language token."""
+        lt = np.ascontiguousarray(lang_tokens, dtype=np.int32)
+        out = np.zeros(self.batch, dtype=np.int32)
+        probs = np.zeros((self.batch, len(lt)), dtype=np.float32) if want_probs else None
+        self._chk(self.L.nh_detect_language(self._h, _ip(lt), len(lt), _ip(out), _fp(probs) if want_probs else None))
+        return out.tolist(), probs
+
+    def set_languages(self, langs: Optional[Sequence[int]]):
+        if langs is None:
+            self._chk(self.L.nh_set_languages(self._h, None))
+        else:
+            a = np.ascontiguousarray(langs, dtype=np.int32)
+            self._chk(self.L.nh_set_languages(self._h, _ip(a)))
 
     def reset(self):
         self._chk(self.L.nh_reset(self._h))

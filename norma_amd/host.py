@@ -87,6 +87,8 @@ def _lib():
         L.nm_definition_blocking_try_to_model_from_dir.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float), C.c_int, C.c_char_p,
                                                                    C.c_int, C.c_char_p, C.c_int]
         L.nm_model_last_text.argtypes = [vp, C.c_char_p, C.c_int]
+        L.nm_model_enable_language_detection.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
+        L.nm_model_language_token.argtypes = [vp]
         L.nm_model_free.argtypes = [vp]
         L.nm_model_transcribe.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_int32), C.c_int,
                                           C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.c_char_p, C.c_int]
@@ -138,6 +140,15 @@ class Model:
                 cur.append(t)
         return segs
 
+    def enable_language_detection(self, lang_tokens: Sequence[int]):
+        """multilingual LanguageState::Detect: tokens of `Language::iter()` (languages.rs:7-107) in order."""
+        a = np.ascontiguousarray(lang_tokens, dtype=np.int32)
+        _lib().nm_model_enable_language_detection(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), len(a))
+
+    @property
+    def language_token(self) -> int:
+        return int(_lib().nm_model_language_token(self._h))
+
     def last_text(self) -> str:
         """Concatenated text of the last transcribe call (needs a model loaded with a tokenizer)."""
         n = _lib().nm_model_last_text(self._h, None, 0)
@@ -181,10 +192,11 @@ class Definition:
     def data_buffer_size(self) -> int:
         return int(_lib().nm_definition_data_buffer_size(self._h))
 
-    def blocking_try_to_model_from_dir(self, path: str, language: str = "<|en|>", translate: bool = False,
+    def blocking_try_to_model_from_dir(self, path: str, language: Optional[str] = "<|en|>", translate: bool = False,
                                        ctx_len: int = 448) -> Model:
         """Load config.json / tokenizer.json / model.safetensors from a local directory (the files the reference
-        fetches through hf-hub, monolingual.rs:323-345)."""
+        fetches through hf-hub, monolingual.rs:323-345).  language=None: multilingual Definition, the language is
+        detected (multilingual.rs:463-466)."""
         import json
         import os
         with open(os.path.join(path, "config.json")) as f:
@@ -192,7 +204,7 @@ class Definition:
         filt = np.ascontiguousarray(assets_io.mel_filters(n_mel), dtype=np.float32)
         err = C.create_string_buffer(512)
         h = _lib().nm_definition_blocking_try_to_model_from_dir(self._h, path.encode(), filt.ctypes.data_as(C.POINTER(C.c_float)),
-                                                                filt.shape[0], language.encode(), int(translate), err, 512)
+                                                                filt.shape[0], (language or "").encode(), int(translate), err, 512)
         if not h:
             raise WhisperError(err.value.decode())
         return Model(C.c_void_p(h), ctx_len)

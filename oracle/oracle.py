@@ -80,6 +80,8 @@ def lib():
         L.wo_decode.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, C.c_int, ip, dp, dp, fp]
         L.wo_transcribe.argtypes = [C.c_void_p, fp, fp, C.POINTER(C.c_long), C.c_int, C.c_int, C.c_int,
                                     ip, C.c_int, ip, dp, dp]
+        L.wo_detect_language.argtypes = [C.c_void_p, fp, C.c_int, ip, C.c_int, fp]
+        L.wo_set_language.argtypes = [C.c_void_p, C.c_int]
         L.wo_num_threads.restype = C.c_int
         L.wo_set_num_threads.argtypes = [C.c_int]
         # never oversubscribe: GPU boxes expose every host core but grant a 16-core share
@@ -184,6 +186,17 @@ class OracleModel:
         t = np.ascontiguousarray(tokens, dtype=np.int32)
         lib().wo_apply_rules(self._h, _f(p), _i(t), len(t), last_timestamp)
         return p
+
+    def detect_language(self, xa: np.ndarray, lang_tokens):
+        """Model::detect_language (model.rs:194-210) -> (token id, probabilities over lang_tokens)."""
+        xa = np.ascontiguousarray(xa, dtype=np.float32)
+        lt = np.ascontiguousarray(lang_tokens, dtype=np.int32)
+        probs = np.zeros(len(lt), dtype=np.float32)
+        tok = lib().wo_detect_language(self._h, _f(xa), xa.shape[0], _i(lt), len(lt), _f(probs))
+        return int(tok), probs
+
+    def set_language(self, lang_token: int):
+        lib().wo_set_language(self._h, int(lang_token))
 
     def decode(self, xa: np.ndarray, use_kv_cache: bool = True, max_new_tokens: int = 0, want_steps=False):
         xa = np.ascontiguousarray(xa, dtype=np.float32)

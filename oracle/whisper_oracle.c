@@ -753,6 +753,7 @@ void wo_apply_rules(const wo_model *m, float *p, const int *tokens, int n_tokens
 }
 
 /* f32::total_cmp key */
+static inline int32_t total_key(float f);
 static inline int32_t total_key(float f) {
     int32_t b; memcpy(&b, &f, 4);
     return b ^ (int32_t)(((uint32_t)(b >> 31)) >> 1);
@@ -763,6 +764,30 @@ int wo_argmax_total(const float *p, int n) {
     for (int i = 1; i < n; i++) { int32_t k = total_key(p[i]); if (k >= bk) { bk = k; best = i; } }
     return best;
 }
+
+/* ------------------------------------------------------------------------------------------ */
+/* Model::detect_language (model.rs:194-210): one decoder step on [sot], softmax over the       */
+/* language-token logits, stable descending sort by total_cmp -> the FIRST maximum wins          */
+/* ------------------------------------------------------------------------------------------ */
+int wo_detect_language(wo_model *m, const float *xa, int S, const int *lang_tokens, int n_lang, float *probs_out) {
+    int V = m->c.n_vocab, d = m->c.d;
+    int tok = m->tk.sot;
+    float *ys = (float *)xcalloc((size_t)d, sizeof(float));
+    float *logits = (float *)xcalloc((size_t)V, sizeof(float));
+    float *pl = (float *)xcalloc((size_t)n_lang, sizeof(float));
+    decoder_rows(m, &tok, 1, 0, xa, S, 1, ys);
+    wo_final_linear(m, ys, 1, logits);
+    for (int i = 0; i < n_lang; i++) pl[i] = logits[lang_tokens[i]]; /* index_select */
+    softmax_row(pl, n_lang);
+    int best = 0; int32_t bk = total_key(pl[0]);
+    for (int i = 1; i < n_lang; i++) { int32_t k = total_key(pl[i]); if (k > bk) { bk = k; best = i; } }
+    if (probs_out) memcpy(probs_out, pl, sizeof(float) * (size_t)n_lang);
+    int res = lang_tokens[best];
+    free(ys); free(logits); free(pl);
+    return res;
+}
+
+void wo_set_language(wo_model *m, int lang_token) { m->tk.lang = lang_token; } /* LanguageState::set_language_token */
 
 /* ------------------------------------------------------------------------------------------ */
 /* Model::decode at t = 0 (model.rs:279-389)                                                  */
