@@ -172,6 +172,18 @@ def main():
         extra["decode_ms_128"] = tm128["decode_ms"]
 
     if rank == 0:
+        # HBM traffic of the dominant kernel per launch: from the committed rocprofv3 PMC passes (FETCH_SIZE and
+        # WRITE_SIZE collected in separate runs, FETCH_SIZE doubled per the gfx950 correction); counters cannot be
+        # read from inside this process, so this is the last profiled value, not a live one
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")) as f:
+                pj = json.load(f)
+            rows = [v for k, v in pj.items() if k.startswith("gemm256_f16_kernel")]
+            nl = sum(v["launches"] for v in rows)
+            traffic = sum(v["hbm_bytes_corrected"] * v["launches"] for v in rows) / nl if nl else None
+        except Exception:
+            traffic = None
         gemm_tflops = tm["gemm_flops"] / (tm["gemm_ms"] * 1e-3) / 1e12 if tm["gemm_ms"] > 0 else 0.0
         peak = 2500.0  # dense fp16 MFMA peak of MI355X (MI355X_MICROARCH.md), TFLOP/s
         out = {
@@ -186,7 +198,9 @@ def main():
             "phases_ms": {k: tm[k] for k in ("mel_ms", "encoder_ms", "cross_kv_ms", "decode_ms")},
             "decode_steps": tm["decode_steps"],
             "roofline": {"bound": "mfma", "kernel": "gemm256_f16_kernel", "achieved": gemm_tflops, "peak": peak,
-                         "unit": "TFLOP/s", "frac": gemm_tflops / peak, "traffic": None,
+                         "unit": "TFLOP/s", "frac": gemm_tflops / peak, "traffic": traffic,
+                         "traffic_note": "bytes per launch from profiles/pmc_hbm_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
+                                         "Infinity-Cache hits included); algorithmic bytes per launch are ~0.4-0.7 GB",
                          "launches": tm["gemm_launches"], "avg_launch_ms": tm["gemm_ms"] / max(tm["gemm_launches"], 1),
                          "flops_per_step": tm["gemm_flops"]},
             "extra": extra, "model_build_s": t_build,
