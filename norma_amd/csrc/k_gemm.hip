@@ -336,6 +336,7 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem
     }
 }
 
+template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
     __shared__ __attribute__((aligned(16))) char smem[G2_EPI_BYTES > G2_NSTAGE * G2_STAGE_BYTES ? G2_EPI_BYTES : G2_NSTAGE * G2_STAGE_BYTES];
     const int ntn = p.N / G2_BN, ntm = (p.M + G2_BM - 1) / G2_BM;
@@ -361,12 +362,30 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
     const int wm = w >> 2, wn = w & 3;
     const int fr = lane & 15, fq = lane >> 4;
     f32x4 acc[8][4];
+    if (EPI == EPI_RESID_F32) {
+        // x += A.W + bias: the residual tile and the bias are the INITIAL accumulator, fetched while the first
+        // stages are in flight, so the epilogue is store-only (fire and forget) instead of an HBM-bound
+        // read-modify-write that nothing overlaps (one workgroup per CU)
 #pragma unroll
-    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 4; j++) {
+            const int n = n0 + wn * 64 + 16 * j + 4 * fq;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (p.bias) bv = *reinterpret_cast<const f32x4 *>(p.bias + n);
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int seg = (p.epi == EPI_F16 || p.epi == EPI_GELU_F16) ? n0 / p.seg_n : 0;
-    const bool vt = (p.epi == EPI_F16 && seg == p.vt_seg);
+            for (int i = 0; i < 8; i++) {
+                int m = m0 + wm * 128 + 16 * i + fr;
+                if (m >= p.M) m = p.M - 1;
+                acc[i][j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.out[0]) + (long)m * p.ldo + n) + bv;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int seg = (EPI == EPI_F16 || EPI == EPI_GELU_F16) ? n0 / p.seg_n : 0;
+    const bool vt = (EPI == EPI_F16 && seg == p.vt_seg);
     if (vt) gemm256_mainloop<false>(p, smem, m0, n0, acc);
     else gemm256_mainloop<true>(p, smem, m0, n0, acc);
 
@@ -412,7 +431,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
         }
         return;
     }
-    if (p.epi == EPI_F16 || p.epi == EPI_GELU_F16) {
+    if (EPI == EPI_F16 || EPI == EPI_GELU_F16) {
         // lane holds columns n = nb + 4 fq + r of row m = mb + fr: image [m = 128][n = 64] fp16
         half_t *ob = reinterpret_cast<half_t *>(seg == 0 ? p.out[0] : seg == 1 ? p.out[1] : p.out[2]);
 #pragma unroll
@@ -422,7 +441,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 f32x4 v = acc[i][j] + bv;
-                if (p.epi == EPI_GELU_F16) {
+                if (EPI == EPI_GELU_F16) {
                     v[0] = gelu_tanh_f(v[0]); v[1] = gelu_tanh_f(v[1]); v[2] = gelu_tanh_f(v[2]); v[3] = gelu_tanh_f(v[3]);
                 }
                 half4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
@@ -456,18 +475,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
             const int m = m0 + wm * 128 + 16 * i + fr;
             if (m >= p.M) continue;
             f32x4 v = acc[i][j] + bv;
-            if (p.epi == EPI_F16 || p.epi == EPI_GELU_F16) {
-                if (p.epi == EPI_GELU_F16) {
+            if (EPI == EPI_F16 || EPI == EPI_GELU_F16) {
+                if (EPI == EPI_GELU_F16) {
                     v[0] = gelu_tanh_f(v[0]); v[1] = gelu_tanh_f(v[1]);
                     v[2] = gelu_tanh_f(v[2]); v[3] = gelu_tanh_f(v[3]);
                 }
                 half_t *dst = obase + out_row(p, m) * p.ldo + (n - seg * p.seg_n);
                 half4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 *reinterpret_cast<half4 *>(dst) = hv;
-            } else if (p.epi == EPI_RESID_F32) {
-                float *dst = reinterpret_cast<float *>(p.out[0]) + (long)m * p.ldo + n;
-                f32x4 x = *reinterpret_cast<const f32x4 *>(dst);
-                *reinterpret_cast<f32x4 *>(dst) = x + v;
+            } else if (EPI == EPI_RESID_F32) {
+                // acc already holds x + bias + A.W (the accumulator was initialised with the residual tile)
+                *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out[0]) + (long)m * p.ldo + n) = acc[i][j];
             } else {  // EPI_CONV2_F32
                 int s = m % p.S;
                 f32x4 pe = *reinterpret_cast<const f32x4 *>(p.pos + (long)s * p.N + n);
@@ -485,7 +503,13 @@ void launch_gemm(const GemmParams &p, hipStream_t st) {
     const bool seg_ok = (p.epi != EPI_F16 && p.epi != EPI_GELU_F16) || (p.seg_n % G2_BN == 0);
     if (!g_gemm_small_only && p.N % G2_BN == 0 && p.K % G2_BK == 0 && seg_ok && p.M >= G2_BM) {
         int ntn = p.N / G2_BN, ntm = (p.M + G2_BM - 1) / G2_BM;
-        hipLaunchKernelGGL(gemm256_f16_kernel, dim3(ntn * ntm), dim3(512), 0, st, p);
+        const dim3 grid(ntn * ntm), block(512);
+        switch (p.epi) {  // one instantiation per epilogue: a single accumulator-init / store path each (register pressure)
+            case EPI_F16: hipLaunchKernelGGL(gemm256_f16_kernel<EPI_F16>, grid, block, 0, st, p); break;
+            case EPI_GELU_F16: hipLaunchKernelGGL(gemm256_f16_kernel<EPI_GELU_F16>, grid, block, 0, st, p); break;
+            case EPI_RESID_F32: hipLaunchKernelGGL(gemm256_f16_kernel<EPI_RESID_F32>, grid, block, 0, st, p); break;
+            default: hipLaunchKernelGGL(gemm256_f16_kernel<EPI_CONV2_F32>, grid, block, 0, st, p); break;
+        }
         return;
     }
     int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
