@@ -269,6 +269,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
 #define G2_STAGE_BYTES 32768  // A 16 KiB + B 16 KiB
 #define G2_NSTAGE 4
 #define G2_GM 4
+#ifndef G2_PAIR
+#define G2_PAIR 0
+#endif
+#ifndef G2_PIPE
+#define G2_PIPE 0
+#endif
+#ifndef G2_STAGE_AFTER_READS
+#define G2_STAGE_AFTER_READS 1
+#endif
 // fp16 epilogues go through LDS so that every global store instruction writes whole 128/256-byte rows:
 // per wave a [128][64] image with 136-byte rows (row-major outputs) or a [64][128] image with 264-byte rows (V^T)
 #define G2_EPI_ROW 136
@@ -308,16 +317,8 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem
 #pragma unroll
     for (int j = 0; j < 4; j++) offB[j] = 16384 + (wn * 64 + 16 * j + fr) * 64 + sw;
 
-    stage(0);
-    if (ns > 1) stage(1);
-    if (ns > 2) stage(2);
-    for (int s = 0; s < ns; s++) {
-        const int rem = ns - 1 - s;  // stages issued beyond s (capped at 2 outstanding)
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (s + 3 < ns) stage(s + 3);
+#if G2_PAIR
+    auto compute = [&](int s) {
         const char *ts = smem + (s & (G2_NSTAGE - 1)) * G2_STAGE_BYTES;
         half8 fa[8], fb[4];
 #pragma unroll
@@ -333,7 +334,93 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem
                 else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         __builtin_amdgcn_s_setprio(0);
+    };
+#endif
+#if G2_PIPE
+    // Software-pipelined fragments: the MFMAs of stage s run on registers that were read from LDS during stage s-1,
+    // while the fragments of stage s+1 are being read -- no LDS latency bubble after the barrier (PMC: ~30 % of
+    // wave time was parked in s_waitcnt/s_barrier).  Two named register sets, loop unrolled by two (static indexing).
+    auto read_frags = [&](int s, half8 (&fa)[8], half8 (&fb)[4]) {
+        const char *ts = smem + (s & (G2_NSTAGE - 1)) * G2_STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const half8 *>(ts + offB[j]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) fa[i] = *reinterpret_cast<const half8 *>(ts + offA[i]);
+    };
+    auto mfmas = [&](const half8 (&fa)[8], const half8 (&fb)[4]) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    };
+    half8 fa0[8], fb0[4], fa1[8], fb1[4];
+    stage(0);
+    if (ns > 1) stage(1);
+    if (ns > 2) stage(2);
+    if (ns > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ns > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, fa0, fb0);
+    auto body = [&](int s, half8 (&fa)[8], half8 (&fb)[4], half8 (&na)[8], half8 (&nb)[4]) {
+        const int rem = ns - 1 - s;  // stages after s; s+1 must have landed, s+2 may stay in flight
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (rem >= 1) __builtin_amdgcn_s_barrier();  // every wave's stage s+1 landed; every wave finished READING stage s-1
+        if (s + 3 < ns) stage(s + 3);                 // overwrites the slot of stage s-1
+        if (rem >= 1) read_frags(s + 1, na, nb);
+        mfmas(fa, fb);
+    };
+    for (int s = 0; s < ns; s += 2) {  // ns is even (K % 64 == 0)
+        body(s, fa0, fb0, fa1, fb1);
+        body(s + 1, fa1, fb1, fa0, fb0);
     }
+#elif G2_PAIR
+    // two 32-deep stages per barrier: classic double buffering with 64-deep K-tiles built from the 4 ring slots
+    stage(0); stage(1);
+    for (int s = 0; s < ns; s += 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 2 < ns) { stage(s + 2); stage(s + 3); }
+        compute(s);
+        compute(s + 1);
+    }
+#else
+    stage(0);
+    if (ns > 1) stage(1);
+    if (ns > 2) stage(2);
+    for (int s = 0; s < ns; s++) {
+        const int rem = ns - 1 - s;  // stages issued beyond s (capped at 2 outstanding)
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const char *ts = smem + (s & (G2_NSTAGE - 1)) * G2_STAGE_BYTES;
+        half8 fa[8], fb[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const half8 *>(ts + offB[j]);
+#pragma unroll
+        for (int i = 0; i < 8; i++) fa[i] = *reinterpret_cast<const half8 *>(ts + offA[i]);
+#if G2_STAGE_AFTER_READS
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (s + 3 < ns) stage(s + 3);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        __builtin_amdgcn_s_setprio(0);
+    }
+#endif
 }
 
 template <int EPI>

@@ -284,3 +284,28 @@ def test_distil_large_v3_b32_size_independent_properties():
     assert r2[1]["tokens"] == r32[17]["tokens"] and r2[1]["no_speech_prob"] == r32[17]["no_speech_prob"]
     assert np.isfinite(enc5).all() and abs(float(enc5.std()) - 1.0) < 0.25
     hm.close()
+
+
+def test_batch_64_paths_are_batch_invariant_and_match_the_oracle():
+    """max_batch = 64 (BASELINE.json config 5 uses b64): exercises the 4-column-block decoder kernels; every clip must
+    give exactly what it gives alone, and clip 0 must match the oracle."""
+    O = _oracle()
+    name = "test-d256-mel128"
+    cfg = config.preset(name)
+    tk = common.tokens_for(name)
+    script = common.transcript_script(tk, n_segments=3, words_per_segment=6, seed=21)
+    over = common.scripted_overrides(cfg, tk, script)
+    hm = common.build_hip(cfg, tk, seed=1, overrides=over, max_batch=64)
+    clips = [synth.synth_pcm(k, 480000 if k % 3 else 320000) for k in range(64)]
+    hm.logmel(clips); hm.encode()
+    r64 = hm.decode_greedy()
+    h1 = common.build_hip(cfg, tk, seed=1, overrides=over, max_batch=1)
+    for b in (0, 17, 63):
+        h1.logmel([clips[b]]); h1.encode()
+        r1 = h1.decode_greedy()[0]
+        assert r1["tokens"] == r64[b]["tokens"] and r1["avg_logprob"] == r64[b]["avg_logprob"]
+    om = common.build_oracle(cfg, tk, seed=1, overrides=over)
+    ref = om.decode(om.encoder_forward(O.pcm_to_mel(clips[0], assets_io.mel_filters(cfg.num_mel_bins))))
+    assert r64[0]["tokens"] == ref["tokens"] == [tk.sot, tk.en, tk.transcribe] + script
+    assert abs(r64[0]["avg_logprob"] - ref["avg_logprob"]) <= 5e-3
+    hm.close(); h1.close(); om.close()
