@@ -51,13 +51,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (one-GPU box): NORMA_BENCH_BACKEND=gloo and NORMA_BENCH_FORCE_DEVICE=0 let several ranks share a card
+    backend = os.environ.get("NORMA_BENCH_BACKEND", "nccl")
+    if "NORMA_BENCH_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["NORMA_BENCH_FORCE_DEVICE"])
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if hip.device_count() < 1:
         raise RuntimeError("bench.py needs an MI355X; norma_amd has no CPU fallback")
 
@@ -142,7 +147,7 @@ def main():
     dt = time.perf_counter() - t0
     tm = hm.timings()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     audio_s = world * B * 30.0 * args.steps
