@@ -275,6 +275,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
 #ifndef G2_PIPE
 #define G2_PIPE 0
 #endif
+#ifndef G2_SPREAD
+#define G2_SPREAD 0
+#endif
 #ifndef G2_STAGE_AFTER_READS
 #define G2_STAGE_AFTER_READS 1
 #endif
@@ -309,6 +312,12 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem
             __builtin_amdgcn_global_load_lds((gbl_void *)(wg[i] + (long)s * G2_BK), (lds_void *)(lb + 8192 * i), 16, 0, 0);
         }
     };
+    auto stage_piece = [&](int s, int piece) {  // piece 0..3: A rows 0-127, B rows 0-127, A rows 128-255, B rows 128-255
+        char *la = smem + (s & (G2_NSTAGE - 1)) * G2_STAGE_BYTES + wbase, *lb = la + 16384;
+        const int i = piece >> 1;
+        if (piece & 1) __builtin_amdgcn_global_load_lds((gbl_void *)(wg[i] + (long)s * G2_BK), (lds_void *)(lb + 8192 * i), 16, 0, 0);
+        else __builtin_amdgcn_global_load_lds((gbl_void *)(ag[i] + (long)s * G2_BK), (lds_void *)(la + 8192 * i), 16, 0, 0);
+    };
     // fragment offsets inside a stage: row r, chunk fq swizzled; A rows wm*128 + 16 i + fr, B rows wn*64 + 16 j + fr
     int offA[8], offB[4];
     const int sw = (fq ^ ((-(fr >> 2)) & 3)) << 4;
@@ -336,7 +345,59 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem
         __builtin_amdgcn_s_setprio(0);
     };
 #endif
-#if G2_PIPE
+#if G2_PIPE == 2
+    // Partial software pipelining of the fragments: the 4 B fragments and the first 2 A fragments of stage s+1 are
+    // read from LDS during stage s (24 extra VGPRs), so the first 8 MFMAs after a barrier need no LDS data; the
+    // other 6 A fragments are read behind them.  (PMC: ~30 % of wave time was parked in s_waitcnt/s_barrier; the
+    // fully double-buffered variant G2_PIPE=1 needs 48 extra VGPRs and spills.)
+    constexpr int NPRE = 2;
+    auto mfma_row = [&](int i, const half8 &a, const half8 (&fb)[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], a, acc[i][j], 0, 0, 0);
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    half8 pb0[4], pa0[NPRE], pb1[4], pa1[NPRE];
+    auto pre_read = [&](int s, half8 (&pa)[NPRE], half8 (&pb)[4]) {
+        const char *ts = smem + (s & (G2_NSTAGE - 1)) * G2_STAGE_BYTES;
+#pragma unroll
+        for (int j = 0; j < 4; j++) pb[j] = *reinterpret_cast<const half8 *>(ts + offB[j]);
+#pragma unroll
+        for (int i = 0; i < NPRE; i++) pa[i] = *reinterpret_cast<const half8 *>(ts + offA[i]);
+    };
+    stage(0);
+    if (ns > 1) stage(1);
+    if (ns > 2) stage(2);
+    if (ns > 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (ns > 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    pre_read(0, pa0, pb0);
+    auto body = [&](int s, half8 (&pa)[NPRE], half8 (&pb)[4], half8 (&na)[NPRE], half8 (&nb)[4]) {
+        const int rem = ns - 1 - s;
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (rem >= 1) __builtin_amdgcn_s_barrier();
+        const char *ts = smem + (s & (G2_NSTAGE - 1)) * G2_STAGE_BYTES;
+        half8 fa[8 - NPRE];
+#pragma unroll
+        for (int i = NPRE; i < 8; i++) fa[i - NPRE] = *reinterpret_cast<const half8 *>(ts + offA[i]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 3 < ns) stage(s + 3);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < NPRE; i++) mfma_row(i, pa[i], pb);
+        if (rem >= 1) pre_read(s + 1, na, nb);
+#pragma unroll
+        for (int i = NPRE; i < 8; i++) mfma_row(i, fa[i - NPRE], pb);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    for (int s = 0; s < ns; s += 2) {  // ns is even (K % 64 == 0)
+        body(s, pa0, pb0, pa1, pb1);
+        body(s + 1, pa1, pb1, pa0, pb0);
+    }
+#elif G2_PIPE
     // Software-pipelined fragments: the MFMAs of stage s run on registers that were read from LDS during stage s-1,
     // while the fragments of stage s+1 are being read -- no LDS latency bubble after the barrier (PMC: ~30 % of
     // wave time was parked in s_waitcnt/s_barrier).  Two named register sets, loop unrolled by two (static indexing).
@@ -406,6 +467,24 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem
         for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const half8 *>(ts + offB[j]);
 #pragma unroll
         for (int i = 0; i < 8; i++) fa[i] = *reinterpret_cast<const half8 *>(ts + offA[i]);
+#if G2_SPREAD
+        // the four LDS-DMA issues of stage s+3 are spread over the MFMA rows (one per 8 MFMAs) instead of a burst
+        // that stalls both waves of a SIMD at the same time right after the barrier
+        const bool more = s + 3 < ns;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (SWAP) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+            if (i & 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (more) stage_piece(s + 3, i >> 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#else
 #if G2_STAGE_AFTER_READS
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -419,6 +498,7 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem
                 else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         __builtin_amdgcn_s_setprio(0);
+#endif
     }
 #endif
 }
