@@ -309,3 +309,36 @@ def test_batch_64_paths_are_batch_invariant_and_match_the_oracle():
     assert r64[0]["tokens"] == ref["tokens"] == [tk.sot, tk.en, tk.transcribe] + script
     assert abs(r64[0]["avg_logprob"] - ref["avg_logprob"]) <= 5e-3
     hm.close(); h1.close(); om.close()
+
+
+def test_clip_shorter_than_one_hop_uses_the_1500_frame_path():
+    """pcm_to_mel yields 1500 frames (not 3000) for a clip shorter than one hop (160 samples), so the encoder sees
+    750 positions (SURVEY.md 3.3[A]-2); 750 is not a multiple of 4, which exercises the scalar V^T tail stores."""
+    O = _oracle()
+    name = "test-d128"
+    cfg = config.preset(name)
+    tk = common.tokens_for(name)
+    script = common.transcript_script(tk, n_segments=2, words_per_segment=3)
+    over = common.scripted_overrides(cfg, tk, script)
+    om = common.build_oracle(cfg, tk, overrides=over)
+    hm = common.build_hip(cfg, tk, overrides=over, max_batch=2)
+    filt = assets_io.mel_filters(cfg.num_mel_bins)
+    clips = [synth.synth_pcm(0, 100), synth.synth_pcm(1, 159)]
+    hm.logmel(clips)
+    hm.encode()
+    res = hm.decode_greedy()
+    for b, c in enumerate(clips):
+        mel = O.pcm_to_mel(c, filt)
+        assert mel.shape[1] == 1500
+        assert np.abs(hm.get_mel(b, frames=1500) - mel).max() <= 2e-5
+        xa = om.encoder_forward(mel)
+        assert xa.shape[0] == 750
+        assert np.abs(hm.encoder_output(b, S=750) - xa).max() <= 2e-3
+        ref = om.decode(xa)
+        assert res[b]["tokens"] == ref["tokens"]
+    # and the context goes back to full-length clips afterwards (the zero framing rows move with the frame count)
+    full = synth.synth_pcm(2)
+    hm.logmel([full]); hm.encode()
+    xa = om.encoder_forward(O.pcm_to_mel(full, filt))
+    assert np.abs(hm.encoder_output(0) - xa).max() <= 2e-3
+    hm.close(); om.close()
