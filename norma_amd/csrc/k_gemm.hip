@@ -312,12 +312,14 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem
             __builtin_amdgcn_global_load_lds((gbl_void *)(wg[i] + (long)s * G2_BK), (lds_void *)(lb + 8192 * i), 16, 0, 0);
         }
     };
+#if G2_SPREAD
     auto stage_piece = [&](int s, int piece) {  // piece 0..3: A rows 0-127, B rows 0-127, A rows 128-255, B rows 128-255
         char *la = smem + (s & (G2_NSTAGE - 1)) * G2_STAGE_BYTES + wbase, *lb = la + 16384;
         const int i = piece >> 1;
         if (piece & 1) __builtin_amdgcn_global_load_lds((gbl_void *)(wg[i] + (long)s * G2_BK), (lds_void *)(lb + 8192 * i), 16, 0, 0);
         else __builtin_amdgcn_global_load_lds((gbl_void *)(ag[i] + (long)s * G2_BK), (lds_void *)(la + 8192 * i), 16, 0, 0);
     };
+#endif
     // fragment offsets inside a stage: row r, chunk fq swizzled; A rows wm*128 + 16 i + fr, B rows wn*64 + 16 j + fr
     int offA[8], offB[4];
     const int sw = (fq ^ ((-(fr >> 2)) & 3)) << 4;
