@@ -275,6 +275,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
 #ifndef G2_PIPE
 #define G2_PIPE 0
 #endif
+#ifndef G2_ABL
+#define G2_ABL 0
+#endif
 #ifndef G2_SPREAD
 #define G2_SPREAD 0
 #endif
@@ -288,29 +291,47 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
 #define G2_EPI_WAVE 17408  // max(128 * 136, 64 * 264)
 #define G2_EPI_BYTES (8 * G2_EPI_WAVE)
 
-template <bool SWAP>
+// WM = 2: 256 x 256 tile, 8 waves (2 x 4), 4-slot ring of 32 KiB, one workgroup per CU.
+// WM = 1: 128 x 256 tile, 4 waves (1 x 4), 3-slot ring of 24 KiB, TWO independent workgroups per CU: while one waits at
+//         its barrier / for its DMA, the other one's MFMAs keep the matrix pipes busy (same 128 x 64 tile per wave).
+template <bool SWAP, int WM>
 __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem, int m0, int n0, f32x4 (&acc)[8][4]) {
+    constexpr int NT = 256 * WM;                     // threads
+    constexpr int ABYTES = 8192 * WM;                // A image per stage: (128 WM) rows x 64 B
+    constexpr int STAGE_BYTES = ABYTES + 16384;      // + B image: 256 rows x 64 B
+    constexpr int NSTAGE = WM == 2 ? 4 : 3;
+    constexpr int NB = 4 / WM;                       // LDS-DMA instructions per thread for the B image (A: always 2)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wm = w >> 2, wn = w & 3;
+    const int wm = WM == 2 ? (w >> 2) : 0, wn = w & 3;
     const int fr = lane & 15, fq = lane >> 4;
-    // staging: slot s = tid + 512 i (i = 0, 1): row = s >> 2, chunk' = s & 3
-    const half_t *ag[2], *wg[2];
+    // staging: slot s = tid + NT i: row = s >> 2, chunk' = s & 3
+    const half_t *ag[2], *wg[NB];
 #pragma unroll
     for (int i = 0; i < 2; i++) {
-        int row = (tid >> 2) + 128 * i;
+        int row = (tid >> 2) + (NT / 4) * i;
         int c = (tid & 3) ^ ((-(row >> 2)) & 3);
         ag[i] = a_row_ptr(p, m0 + row) + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        int row = (tid >> 2) + (NT / 4) * i;
+        int c = (tid & 3) ^ ((-(row >> 2)) & 3);
         wg[i] = p.W + (long)(n0 + row) * p.K + c * 8;
     }
     const int ns = p.K / G2_BK;
     const int wbase = __builtin_amdgcn_readfirstlane(w) * 1024;
+    auto slot_of = [&](int s) { return WM == 2 ? (s & 3) : (s % 3); };
     auto stage = [&](int s) {
-        char *la = smem + (s & (G2_NSTAGE - 1)) * G2_STAGE_BYTES + wbase, *lb = la + 16384;
+#if G2_ABL & 1  // ablation (tools/gbench only): no LDS-DMA -- s = 0 (stage once, stay in cache) keeps results meaningless
+        if (s >= NSTAGE) return;
+#endif
+        char *la = smem + slot_of(s) * STAGE_BYTES + wbase, *lb = la + ABYTES;
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-            __builtin_amdgcn_global_load_lds((gbl_void *)(ag[i] + (long)s * G2_BK), (lds_void *)(la + 8192 * i), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gbl_void *)(wg[i] + (long)s * G2_BK), (lds_void *)(lb + 8192 * i), 16, 0, 0);
-        }
+        for (int i = 0; i < 2; i++)
+            __builtin_amdgcn_global_load_lds((gbl_void *)(ag[i] + (long)s * G2_BK), (lds_void *)(la + NT * 16 * i), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; i++)
+            __builtin_amdgcn_global_load_lds((gbl_void *)(wg[i] + (long)s * G2_BK), (lds_void *)(lb + NT * 16 * i), 16, 0, 0);
     };
 #if G2_SPREAD
     auto stage_piece = [&](int s, int piece) {  // piece 0..3: A rows 0-127, B rows 0-127, A rows 128-255, B rows 128-255
@@ -326,7 +347,7 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem
 #pragma unroll
     for (int i = 0; i < 8; i++) offA[i] = (wm * 128 + 16 * i + fr) * 64 + sw;
 #pragma unroll
-    for (int j = 0; j < 4; j++) offB[j] = 16384 + (wn * 64 + 16 * j + fr) * 64 + sw;
+    for (int j = 0; j < 4; j++) offB[j] = ABYTES + (wn * 64 + 16 * j + fr) * 64 + sw;
 
 #if G2_PAIR
     auto compute = [&](int s) {
@@ -456,19 +477,32 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem
 #else
     stage(0);
     if (ns > 1) stage(1);
-    if (ns > 2) stage(2);
+    if (WM == 2 && ns > 2) stage(2);
+    half8 fa[8], fb[4];
     for (int s = 0; s < ns; s++) {
-        const int rem = ns - 1 - s;  // stages issued beyond s (capped at 2 outstanding)
-        if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int rem = ns - 1 - s;  // stages issued beyond s; WM=2 keeps 2 of them in flight (4 DMA each), WM=1 one (6 DMA)
+        if (WM == 2) {
+            if (rem >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            if (rem >= 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#if !(G2_ABL & 4)
         __builtin_amdgcn_s_barrier();
-        const char *ts = smem + (s & (G2_NSTAGE - 1)) * G2_STAGE_BYTES;
-        half8 fa[8], fb[4];
+#endif
+        const char *ts = smem + slot_of(s) * STAGE_BYTES;
+#if G2_ABL & 2  // ablation: no LDS fragment reads after the first stage
+        if (s == 0) {
+#endif
 #pragma unroll
         for (int j = 0; j < 4; j++) fb[j] = *reinterpret_cast<const half8 *>(ts + offB[j]);
 #pragma unroll
         for (int i = 0; i < 8; i++) fa[i] = *reinterpret_cast<const half8 *>(ts + offA[i]);
+#if G2_ABL & 2
+        }
+#endif
 #if G2_SPREAD
         // the four LDS-DMA issues of stage s+3 are spread over the MFMA rows (one per 8 MFMAs) instead of a burst
         // that stalls both waves of a SIMD at the same time right after the barrier
@@ -490,7 +524,7 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem
 #if G2_STAGE_AFTER_READS
         __builtin_amdgcn_sched_barrier(0);
 #endif
-        if (s + 3 < ns) stage(s + 3);
+        if (s + NSTAGE - 1 < ns) stage(s + NSTAGE - 1);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 8; i++)
@@ -505,10 +539,153 @@ __device__ __forceinline__ void gemm256_mainloop(const GemmParams &p, char *smem
 #endif
 }
 
-template <int EPI>
-__global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[G2_EPI_BYTES > G2_NSTAGE * G2_STAGE_BYTES ? G2_EPI_BYTES : G2_NSTAGE * G2_STAGE_BYTES];
-    const int ntn = p.N / G2_BN, ntm = (p.M + G2_BM - 1) / G2_BM;
+// ---------------------------------------------------------------------------------------------------
+// Ping-pong main loop of the 256 x 256 tile (K % 128 == 0): the 8-phase schedule of the CDNA4 playbook
+// (cdna_hip_programming.md, "The 256^2 8-phase template"), restated for this kernel's operand layout.
+//
+//  * BK = 64 K-tiles in two 64 KiB LDS buffers, each cut into four 16 KiB half-tiles A0 A1 B0 B1.  Half-tile Ah holds,
+//    for BOTH wave rows, the h-th 64 rows of the wave's 128 (LDS row l <-> tile row (l >> 6) * 128 + 64 h + (l & 63));
+//    Bh the h-th 32 columns of each wave column's 64 (l <-> (l >> 5) * 64 + 32 h + (l & 31)).  The permutation lives
+//    in the per-lane SOURCE address of the LDS-DMA, so the wave -> output mapping (and every epilogue) is unchanged.
+//  * a K-tile is four phases = the four 64 x 32 quadrants of the wave's 128 x 64 output, 16 MFMAs each:
+//        q0 (m0,n0): reads A0 (8 ds_read_b128) + B0 (4)    q1 (m0,n1): reads B1 (4)
+//        q2 (m1,n1): reads A1 (8)                          q3 (m1,n0): no reads (B0 fragments are kept)
+//    so the half-tiles of a buffer die one after the other (A0, B0 after q0; B1 after q1; A1 after q2) and each is
+//    re-staged for the K-tile after next two or three phases after its last read, FIVE phases before its first use:
+//        q2: A0(t+2)   q3: B0(t+2)   q0: B1(t+1)   q1: A1(t+1)         (one half-tile = 2 LDS-DMA per thread per phase)
+//  * the two waves of a SIMD (wave rows wr = 0 / 1) run half a phase apart (one extra s_barrier for wr = 1 up front):
+//        phase = [ds_read, LDS-DMA issue, counted vmcnt] s_barrier [lgkmcnt(0), 16 MFMA] s_barrier
+//    so in every barrier interval one wave of each SIMD issues MFMAs while the other one reads LDS: the matrix pipe is
+//    fed by one of them at all times instead of both reading, then both multiplying.
+//  * RAW: the vmcnt that retires a half-tile sits before the FIRST barrier of the phase before its first read (then the
+//    lagging group's part has landed too before the leading group reads); WAR: >= 2 phases between last read and re-stage.
+//    In steady state four half-tiles stay in flight across every wait: vmcnt(8), never 0 inside the loop.
+// ---------------------------------------------------------------------------------------------------
+#define PP_BUF 65536
+#define PP_HT 16384
+
+template <bool SWAP>
+__device__ __forceinline__ void gemm256_pingpong(const GemmParams &p, char *smem, int m0, int n0, f32x4 (&acc)[8][4]) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wr = w >> 2, wc = w & 3;
+    const int fr = lane & 15, fq = lane >> 4;
+    // staging: half-tile slot s = tid + 512 i (i = 0, 1): LDS row l = s >> 3 = (tid >> 3) + 64 i, chunk' = tid & 7,
+    // source chunk = chunk' ^ ((l >> 1) & 7) (64 i leaves the swizzle unchanged)
+    const int lrow = tid >> 3;
+    const int csrc = ((tid & 7) ^ ((lrow >> 1) & 7)) * 8;
+    // 32-bit element offsets from the (scalar) operand bases: 8 VGPRs instead of 16 for the eight source rows
+    unsigned ag[2][2], wg[2][2];  // [h][i]
+#pragma unroll
+    for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            ag[h][i] = (unsigned)(a_row_ptr(p, m0 + i * 128 + h * 64 + lrow) - p.A) + csrc;
+            const int l = lrow + 64 * i;
+            wg[h][i] = (unsigned)(n0 + (l >> 5) * 64 + h * 32 + (l & 31)) * (unsigned)p.K + csrc;
+        }
+    const int nt = p.K >> 6;
+    char *const wbase = smem + __builtin_amdgcn_readfirstlane(w) * 1024;
+    // which: 0 A0, 1 B0, 2 B1, 3 A1 (the issue order of a K-tile)
+    auto stage = [&](int t, int which) {
+        const int h = (which >> 1) & 1;            // A0 0, B0 0, B1 1, A1 1
+        const bool isB = which == 1 || which == 2;
+        char *dst = wbase + (t & 1) * PP_BUF + (isB ? 2 * PP_HT : 0) + h * PP_HT;
+        const unsigned ko = (unsigned)t * 64u;
+        if (isB) {
+            __builtin_amdgcn_global_load_lds((gbl_void *)(p.W + (size_t)(wg[h][0] + ko)), (lds_void *)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(p.W + (size_t)(wg[h][1] + ko)), (lds_void *)(dst + 8192), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((gbl_void *)(p.A + (size_t)(ag[h][0] + ko)), (lds_void *)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gbl_void *)(p.A + (size_t)(ag[h][1] + ko)), (lds_void *)(dst + 8192), 16, 0, 0);
+        }
+    };
+    // fragment read offsets inside a half-tile: row r, chunk 4 ks + fq, swizzle (r >> 1) & 7 == (fr >> 1) for every fragment
+    // (the ks = 1 chunk is the ks = 0 address with bit 6 flipped: one per-lane base per k-step, everything else is an
+    // immediate offset of the ds_read)
+    const int offA0 = (wr * 64 + fr) * 128 + ((fq ^ (fr >> 1)) << 4);  // + 2048 i (i = 0..3)
+    const int offB0 = (wc * 32 + fr) * 128 + ((fq ^ (fr >> 1)) << 4);  // + 2048 j (j = 0..1)
+    const char *const pa[2] = {smem + offA0, smem + (offA0 ^ 64)};
+    const char *const pb[2] = {smem + offB0, smem + (offB0 ^ 64)};
+    half8 fa[4][2], fb[4][2];  // fa[i][ks]: current m-half; fb[j][ks]: j < 2 n0, j >= 2 n1
+
+    // one phase.  Q: quadrant; BUF: LDS buffer of the K-tile being multiplied; t: that K-tile; WAIT: vmcnt count
+    // (< 0: no wait); issue: re-stage the half-tile this phase is responsible for (tile index st)
+#define PP_PHASE(Q, BUF, WAIT, DO_ISSUE, ST)                                                                             \
+    {                                                                                                                    \
+        constexpr int tb_ = (BUF) * PP_BUF;                                                                              \
+        if ((Q) == 0) {                                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++)             \
+                fb[j][ks] = *reinterpret_cast<const half8 *>(pb[ks] + (tb_ + 2 * PP_HT + 2048 * j));                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                           \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++)             \
+                fa[i][ks] = *reinterpret_cast<const half8 *>(pa[ks] + (tb_ + 2048 * i));                                \
+        } else if ((Q) == 1) {                                                                                           \
+            _Pragma("unroll") for (int j = 0; j < 2; j++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++)             \
+                fb[2 + j][ks] = *reinterpret_cast<const half8 *>(pb[ks] + (tb_ + 3 * PP_HT + 2048 * j));                 \
+        } else if ((Q) == 2) {                                                                                           \
+            _Pragma("unroll") for (int i = 0; i < 4; i++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++)             \
+                fa[i][ks] = *reinterpret_cast<const half8 *>(pa[ks] + (tb_ + PP_HT + 2048 * i));                        \
+        }                                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        if (DO_ISSUE) stage((ST), (Q) == 2 ? 0 : (Q) == 3 ? 1 : (Q) == 0 ? 2 : 3);                                      \
+        if ((WAIT) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                \
+        else if ((WAIT) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                           \
+        else if ((WAIT) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                           \
+        else if ((WAIT) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+        __builtin_amdgcn_s_barrier();                                                                                    \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                                                   \
+        {                                                                                                                \
+            constexpr int ib_ = ((Q) >= 2) ? 4 : 0, jb_ = ((Q) == 1 || (Q) == 2) ? 2 : 0;                                \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ks++) _Pragma("unroll") for (int i = 0; i < 4; i++)             \
+                _Pragma("unroll") for (int j = 0; j < 2; j++) {                                                         \
+                    if (SWAP) acc[ib_ + i][jb_ + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[jb_ + j][ks], fa[i][ks], acc[ib_ + i][jb_ + j], 0, 0, 0); \
+                    else acc[ib_ + i][jb_ + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i][ks], fb[jb_ + j][ks], acc[ib_ + i][jb_ + j], 0, 0, 0);      \
+                }                                                                                                        \
+        }                                                                                                                \
+        __builtin_amdgcn_s_setprio(0);                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                                               \
+        __builtin_amdgcn_s_barrier();                                                                                    \
+    }
+
+    // prologue: K-tile 0 complete, A0 and B0 of K-tile 1 (what phases (-1, 2) and (-1, 3) would have issued)
+    stage(0, 0); stage(0, 1); stage(0, 2); stage(0, 3);
+    stage(1, 0); stage(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");  // A0(0), B0(0) of this wave have landed
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // the stagger: wave row 1 runs half a phase behind
+    // steady state: K-tile pairs (t, t + 1) with t + 3 < nt, i.e. every issue below is in range
+    int t = 0;
+    for (; t + 4 <= nt; t += 2) {
+        PP_PHASE(0, 0, 8, true, t + 1)
+        PP_PHASE(1, 0, 8, true, t + 1)
+        PP_PHASE(2, 0, -1, true, t + 2)
+        PP_PHASE(3, 0, 8, true, t + 2)
+        PP_PHASE(0, 1, 8, true, t + 2)
+        PP_PHASE(1, 1, 8, true, t + 2)
+        PP_PHASE(2, 1, -1, true, t + 3)
+        PP_PHASE(3, 1, 8, true, t + 3)
+    }
+    // last pair (nt - 2, nt - 1): nothing left to issue after A1(nt - 1); the waits count down 8 8 . 4 2 0
+    PP_PHASE(0, 0, 8, true, t + 1)
+    PP_PHASE(1, 0, 8, true, t + 1)
+    PP_PHASE(2, 0, -1, false, 0)
+    PP_PHASE(3, 0, 4, false, 0)
+    PP_PHASE(0, 1, 2, false, 0)
+    PP_PHASE(1, 1, 0, false, 0)
+    PP_PHASE(2, 1, -1, false, 0)
+    PP_PHASE(3, 1, -1, false, 0)
+    if (wr == 0) __builtin_amdgcn_s_barrier();        // balance the barrier count of the stagger
+#undef PP_PHASE
+}
+
+template <int EPI, int WM, bool PP>
+__global__ __launch_bounds__(256 * WM, 2) void gemm256_f16_kernel(GemmParams p) {
+    constexpr int TBM = 128 * WM;
+    constexpr int RING = WM == 2 ? 4 * 32768 : 3 * 24576, EPIB = 4 * WM * G2_EPI_WAVE;
+    __shared__ __attribute__((aligned(16))) char smem[EPIB > RING ? EPIB : RING];
+    const int ntn = p.N / G2_BN, ntm = (p.M + TBM - 1) / TBM;
     const int nwg = ntn * ntm;
     int bid = blockIdx.x;
     {
@@ -521,14 +698,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
     // M-panel from the Infinity Cache with the plain M-major order)
     int tm, tn;
     {
-        const int per_group = G2_GM * ntn;
+        constexpr int GM = G2_GM * (2 / WM);          // 1024 rows of A per group either way
+        const int per_group = GM * ntn;
         const int g = bid / per_group, r = bid - g * per_group;
-        const int gm = min(G2_GM, ntm - g * G2_GM);   // the last group may hold fewer M-panels
-        tn = r / gm; tm = g * G2_GM + (r - tn * gm);
+        const int gm = min(GM, ntm - g * GM);         // the last group may hold fewer M-panels
+        tn = r / gm; tm = g * GM + (r - tn * gm);
     }
-    const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+    const int m0 = tm * TBM, n0 = tn * G2_BN;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int wm = w >> 2, wn = w & 3;
+    const int wm = WM == 2 ? (w >> 2) : 0, wn = w & 3;
     const int fr = lane & 15, fq = lane >> 4;
     f32x4 acc[8][4];
     if (EPI == EPI_RESID_F32) {
@@ -555,8 +733,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_f16_kernel(GemmParams p) {
     }
     const int seg = (EPI == EPI_F16 || EPI == EPI_GELU_F16) ? n0 / p.seg_n : 0;
     const bool vt = (EPI == EPI_F16 && seg == p.vt_seg);
-    if (vt) gemm256_mainloop<false>(p, smem, m0, n0, acc);
-    else gemm256_mainloop<true>(p, smem, m0, n0, acc);
+    if (PP) {
+        if (vt) gemm256_pingpong<false>(p, smem, m0, n0, acc);
+        else gemm256_pingpong<true>(p, smem, m0, n0, acc);
+    } else {
+        if (vt) gemm256_mainloop<false, WM>(p, smem, m0, n0, acc);
+        else gemm256_mainloop<true, WM>(p, smem, m0, n0, acc);
+    }
 
     __builtin_amdgcn_s_barrier();  // every wave has left the staging ring: LDS is free for the epilogue images
     char *img = smem + w * G2_EPI_WAVE;
@@ -671,14 +854,25 @@ static const bool g_gemm_small_only = getenv("NORMA_HIP_GEMM128") != nullptr;  /
 void launch_gemm(const GemmParams &p, hipStream_t st) {
     const bool seg_ok = (p.epi != EPI_F16 && p.epi != EPI_GELU_F16) || (p.seg_n % G2_BN == 0);
     if (!g_gemm_small_only && p.N % G2_BN == 0 && p.K % G2_BK == 0 && seg_ok && p.M >= G2_BM) {
-        int ntn = p.N / G2_BN, ntm = (p.M + G2_BM - 1) / G2_BM;
-        const dim3 grid(ntn * ntm), block(512);
-        switch (p.epi) {  // one instantiation per epilogue: a single accumulator-init / store path each (register pressure)
-            case EPI_F16: hipLaunchKernelGGL(gemm256_f16_kernel<EPI_F16>, grid, block, 0, st, p); break;
-            case EPI_GELU_F16: hipLaunchKernelGGL(gemm256_f16_kernel<EPI_GELU_F16>, grid, block, 0, st, p); break;
-            case EPI_RESID_F32: hipLaunchKernelGGL(gemm256_f16_kernel<EPI_RESID_F32>, grid, block, 0, st, p); break;
-            default: hipLaunchKernelGGL(gemm256_f16_kernel<EPI_CONV2_F32>, grid, block, 0, st, p); break;
+        // NORMA_HIP_GEMM_WM: A/B switch. 3 (default): ping-pong 256 x 256 when K % 128 == 0; 2: single-phase 256 x 256; 1: 128 x 256
+        static const int wm_env = getenv("NORMA_HIP_GEMM_WM") ? atoi(getenv("NORMA_HIP_GEMM_WM")) : 3;
+        const int ntn = p.N / G2_BN;
+#define G2_LAUNCH(WM_, PP_, GRID, BLOCK)                                                                                  \
+        switch (p.epi) { /* one instantiation per epilogue: a single accumulator-init / store path each (registers) */  \
+            case EPI_F16: hipLaunchKernelGGL((gemm256_f16_kernel<EPI_F16, WM_, PP_>), GRID, BLOCK, 0, st, p); break;       \
+            case EPI_GELU_F16: hipLaunchKernelGGL((gemm256_f16_kernel<EPI_GELU_F16, WM_, PP_>), GRID, BLOCK, 0, st, p); break; \
+            case EPI_RESID_F32: hipLaunchKernelGGL((gemm256_f16_kernel<EPI_RESID_F32, WM_, PP_>), GRID, BLOCK, 0, st, p); break; \
+            default: hipLaunchKernelGGL((gemm256_f16_kernel<EPI_CONV2_F32, WM_, PP_>), GRID, BLOCK, 0, st, p); break;      \
         }
+        if (wm_env == 1) {
+            const dim3 grid(ntn * ((p.M + 127) / 128)), block(256);
+            G2_LAUNCH(1, false, grid, block)
+            return;
+        }
+        const dim3 grid(ntn * ((p.M + G2_BM - 1) / G2_BM)), block(512);
+        if (wm_env == 3 && p.K % 128 == 0 && p.K >= 256) { G2_LAUNCH(2, true, grid, block) }
+        else { G2_LAUNCH(2, false, grid, block) }
+#undef G2_LAUNCH
         return;
     }
     int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
