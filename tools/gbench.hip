@@ -15,7 +15,10 @@ __global__ void fill_rand(half_t *p, size_t n, unsigned seed) {
 int main(int argc, char **argv) {
     hipStream_t st; CK(hipStreamCreate(&st));
     const int M = argc > 1 ? atoi(argv[1]) : 48000;
-    struct Shape { int N, K, epi; const char *name; } shapes[] = {
+    struct Shape { int N, K, epi; const char *name; };
+    // gbench M N K epi: one custom shape (N <= 5120, K <= 5120) instead of the encoder's six
+    Shape custom[1] = {{argc > 4 ? atoi(argv[2]) : 0, argc > 4 ? atoi(argv[3]) : 0, argc > 4 ? atoi(argv[4]) : 0, "custom"}};
+    Shape shapes_all[] = {
         {1280, 1280, EPI_RESID_F32, "out-proj  N=1280 K=1280 resid"}, {3840, 1280, EPI_F16, "qkv       N=3840 K=1280 f16+VT"},
         {5120, 1280, EPI_GELU_F16, "fc1       N=5120 K=1280 gelu"}, {1280, 5120, EPI_RESID_F32, "fc2       N=1280 K=5120 resid"},
         {1280, 3840, EPI_CONV2_F32, "conv2     N=1280 K=3840 conv2"}, {2560, 1280, EPI_F16, "cross-kv  N=2560 K=1280 f16"}};
@@ -28,7 +31,10 @@ int main(int argc, char **argv) {
     CK(hipMemset(X, 0, (size_t)M * 1280 * 4)); CK(hipMemset(bias, 0, 5120 * 4)); CK(hipMemset(pos, 0, (size_t)1500 * 1280 * 4));
     CK(hipStreamSynchronize(st));
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    for (auto &s : shapes) {
+    const Shape *shapes = argc > 4 ? custom : shapes_all;
+    const int nshapes = argc > 4 ? 1 : 6;
+    for (int si = 0; si < nshapes; si++) {
+        const Shape &s = shapes[si];
         GemmParams p{};
         p.A = A; p.lda = s.K; p.a_rpb = M; p.W = W; p.bias = bias; p.M = M; p.N = s.N; p.K = s.K; p.epi = s.epi;
         p.out[0] = (s.epi == EPI_RESID_F32 || s.epi == EPI_CONV2_F32) ? (void *)X : (void *)O0; p.out[1] = O1; p.out[2] = O2;
