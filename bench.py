@@ -184,7 +184,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_hbm_traffic.json")) as f:
                 pj = json.load(f)
-            rows = [v for k, v in pj.items() if k.startswith("gemm256_f16_kernel")]
+            rows = [v for k, v in pj.items() if "gemm256_f16_kernel" in k]
             nl = sum(v["launches"] for v in rows)
             traffic = sum(v["hbm_bytes_corrected"] * v["launches"] for v in rows) / nl if nl else None
         except Exception:

@@ -15,10 +15,7 @@
 
 #include "nh_kernels.h"
 
-__device__ __forceinline__ float gelu_tanh_d(float v) {
-    float u = 0.7978845608028654f * v * (1.0f + 0.044715f * v * v);
-    return v / (1.0f + __expf(-2.0f * u));
-}
+__device__ __forceinline__ float gelu_tanh_d(float v) { return gelu_tanh_fast(v); }
 
 // ---------------------------------------------------------------------------------------------------
 // skinny GEMM: y[R][N] = x[R][K] . W[N][K]^T, R <= 64.  Weights are the MFMA A operand (16 rows per
@@ -31,10 +28,11 @@ __device__ __forceinline__ float gelu_tanh_d(float v) {
 // ---------------------------------------------------------------------------------------------------
 #define SK_U 10
 
-// pre != nullptr: bias (and, for SK_RESID_F32, the residual) were fetched at kernel start into pre[0], pre[1]
-__device__ __forceinline__ void skinny_store(const SkinnyParams &p, f32x4 v, int r, int n, const f32x4 *pre = nullptr) {
+// has_pre: bias (and, for SK_RESID_F32, the residual) were fetched at kernel start into pre0, pre1
+__device__ __forceinline__ void skinny_store(const SkinnyParams &p, f32x4 v, int r, int n, bool has_pre = false,
+                                             f32x4 pre0 = (f32x4){0.f, 0.f, 0.f, 0.f}, f32x4 pre1 = (f32x4){0.f, 0.f, 0.f, 0.f}) {
     if (n >= p.N) return;
-    if (pre) v += pre[0];
+    if (has_pre) v += pre0;
     else if (p.bias) {
         if (n + 3 < p.N) v += *reinterpret_cast<const f32x4 *>(p.bias + n);
         else for (int i = 0; i < 4 && n + i < p.N; i++) v[i] += p.bias[n + i];
@@ -48,7 +46,7 @@ __device__ __forceinline__ void skinny_store(const SkinnyParams &p, f32x4 v, int
     // the remaining epilogues have N % 4 == 0
     if (p.epi == SK_RESID_F32) {
         float *dst = reinterpret_cast<float *>(p.out[0]) + (long)r * p.ldo + n;
-        f32x4 x = pre ? pre[1] : *reinterpret_cast<const f32x4 *>(dst);
+        f32x4 x = has_pre ? pre1 : *reinterpret_cast<const f32x4 *>(dst);
         *reinterpret_cast<f32x4 *>(dst) = x + v;
         return;
     }
@@ -169,7 +167,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
         for (int ww = 1; ww < KSPLIT; ww++) v += red[ww][cb][src_lane];
     }
     if (KS == 1) {
-        if (owner) skinny_store(p, v, r, n0 + 4 * nq, can_pre ? pre : nullptr);
+        if (owner) skinny_store(p, v, r, n0 + 4 * nq, can_pre, pre[0], pre[1]);
         return;
     }
     // cross-workgroup split-K: slab[tile][ks][r][nq] (f32x4 as 4 write-through dwords)
@@ -194,7 +192,175 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
 #pragma unroll
         for (int i = 0; i < 4; i++) sum[i] += __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    skinny_store(p, sum, r, n0 + 4 * nq, can_pre ? pre : nullptr);
+    skinny_store(p, sum, r, n0 + 4 * nq, can_pre, pre[0], pre[1]);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LayerNorm fused into the skinny GEMM (K = 128 STEPS, R <= 32): the 5.4 us LayerNorm launch in front of every
+// q|k|v, cross-q and fc1 projection of a decode step is pure latency (160 KB in, 80 KB out), so each workgroup
+// normalises the rows itself while its weight tile is in flight.  Wave w owns K-slice w: its lanes already load
+// exactly the x elements of their B fragments (row 16 cb + fr, columns kbeg + 32 s + 8 fq .. + 8), as f32 from the
+// residual stream; the row statistics meet through LDS (two passes over the register-resident values, the "sliced"
+// summation tree of nh_kernels.h), gamma/beta are staged in LDS once per workgroup.
+// ---------------------------------------------------------------------------------------------------
+template <int NCB, int STEPS>
+__global__ __launch_bounds__(256) void skinny_ln_kernel(SkinnyParams p) {
+    constexpr int K = 128 * STEPS;
+    __shared__ f32x4 red[4][NCB][64];
+    __shared__ float part[2][4][NCB][16];
+    __shared__ __attribute__((aligned(16))) float gb[2][K];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kbeg = w * 32 * STEPS;
+    // weights first: the only HBM stream of the kernel
+    int wrow = n0 + fr; if (wrow >= p.N) wrow = p.N - 1;
+    const half_t *wp = p.W + (long)wrow * K + kbeg + 8 * fq;
+    half8 a[STEPS];
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) a[s] = *reinterpret_cast<const half8 *>(wp + 32 * s);
+    // epilogue operands of the element this thread will own (see skinny_gemm_kernel)
+    f32x4 pre[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    const bool can_pre = (p.N & 3) == 0;
+    if (can_pre) {
+        const int er = tid >> 2, en = n0 + 4 * (tid & 3);
+        if (tid < 64 * NCB && er < p.R && en < p.N) {
+            if (p.bias) pre[0] = *reinterpret_cast<const f32x4 *>(p.bias + en);
+            if (p.epi == SK_RESID_F32) pre[1] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.out[0]) + (long)er * p.ldo + en);
+        }
+    }
+    // the rows, f32
+    f32x4 xv[NCB][STEPS][2];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        int r = 16 * cb + fr; if (r >= p.R) r = p.R - 1;
+        const float *xr = p.ln_x + (long)r * K + kbeg + 8 * fq;
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) {
+            xv[cb][s][0] = *reinterpret_cast<const f32x4 *>(xr + 32 * s);
+            xv[cb][s][1] = *reinterpret_cast<const f32x4 *>(xr + 32 * s + 4);
+        }
+    }
+    for (int c = tid; c < K / 4; c += 256) {
+        reinterpret_cast<f32x4 *>(gb[0])[c] = reinterpret_cast<const f32x4 *>(p.ln_w)[c];
+        reinterpret_cast<f32x4 *>(gb[1])[c] = reinterpret_cast<const f32x4 *>(p.ln_b)[c];
+    }
+    float mean[NCB], inv[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) s1 = ln_sum8(s1, xv[cb][s][0], xv[cb][s][1]);
+        s1 += __shfl_xor(s1, 16); s1 += __shfl_xor(s1, 32);
+        if (fq == 0) part[0][w][cb][fr] = s1;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        mean[cb] = ln_mean((part[0][0][cb][fr] + part[0][1][cb][fr]) + (part[0][2][cb][fr] + part[0][3][cb][fr]), p.ln_rk);
+        float s2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) s2 = ln_sq8(s2, xv[cb][s][0], xv[cb][s][1], mean[cb]);
+        s2 += __shfl_xor(s2, 16); s2 += __shfl_xor(s2, 32);
+        if (fq == 0) part[1][w][cb][fr] = s2;
+    }
+    __syncthreads();
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+        inv[cb] = ln_inv((part[1][0][cb][fr] + part[1][1][cb][fr]) + (part[1][2][cb][fr] + part[1][3][cb][fr]), p.ln_rk);
+        acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+        const int k = kbeg + 32 * s + 8 * fq;
+        const f32x4 g0 = *reinterpret_cast<const f32x4 *>(&gb[0][k]), g1 = *reinterpret_cast<const f32x4 *>(&gb[0][k + 4]);
+        const f32x4 b0 = *reinterpret_cast<const f32x4 *>(&gb[1][k]), b1 = *reinterpret_cast<const f32x4 *>(&gb[1][k + 4]);
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) {
+            const f32x4 o0 = ln_apply(xv[cb][s][0], mean[cb], inv[cb], g0, b0);
+            const f32x4 o1 = ln_apply(xv[cb][s][1], mean[cb], inv[cb], g1, b1);
+            const half8 b = {(half_t)o0[0], (half_t)o0[1], (half_t)o0[2], (half_t)o0[3],
+                             (half_t)o1[0], (half_t)o1[1], (half_t)o1[2], (half_t)o1[3]};
+            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s], b, acc[cb], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) red[w][cb][lane] = acc[cb];
+    __syncthreads();
+    const int r = tid >> 2, nq = tid & 3;
+    if (tid < 64 * NCB && r < p.R) {
+        const int src_lane = 16 * nq + (r & 15), cb = r >> 4;
+        f32x4 v = red[0][cb][src_lane];  // same association as skinny_gemm_kernel: the two forms give identical bits
+#pragma unroll
+        for (int ww = 1; ww < 4; ww++) v += red[ww][cb][src_lane];
+        skinny_store(p, v, r, n0 + 4 * nq, can_pre, pre[0], pre[1]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same LayerNorm with 16 consecutive lanes per row (lane t = 4 w + fq of the sliced tree): stand-alone kernel and
+// the staging pass of the logits kernel.  K = 128 steps, steps <= 10; loads are unconditional and clamped.
+// ---------------------------------------------------------------------------------------------------
+#define LN_MAX_STEPS 10
+struct SlicedRow { f32x4 v[LN_MAX_STEPS][2]; float mean, inv; };
+
+__device__ __forceinline__ void sliced_row_stats(SlicedRow &sr, const float *__restrict__ xrow, int K, float rk, int t16) {
+    const int steps = K >> 7, w = t16 >> 2, fq = t16 & 3;
+    const float *xr = xrow + w * 32 * steps + 8 * fq;
+    float s1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < LN_MAX_STEPS; s++) {
+        const int sc = s < steps ? s : steps - 1;
+        sr.v[s][0] = *reinterpret_cast<const f32x4 *>(xr + 32 * sc);
+        sr.v[s][1] = *reinterpret_cast<const f32x4 *>(xr + 32 * sc + 4);
+    }
+#pragma unroll
+    for (int s = 0; s < LN_MAX_STEPS; s++)
+        if (s < steps) s1 = ln_sum8(s1, sr.v[s][0], sr.v[s][1]);
+    s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);   // the four lanes of a slice: (l0 + l1) + (l2 + l3)
+    s1 += __shfl_xor(s1, 4); s1 += __shfl_xor(s1, 8);   // the four slices: (p0 + p1) + (p2 + p3)
+    sr.mean = ln_mean(s1, rk);
+    float s2 = 0.f;
+#pragma unroll
+    for (int s = 0; s < LN_MAX_STEPS; s++)
+        if (s < steps) s2 = ln_sq8(s2, sr.v[s][0], sr.v[s][1], sr.mean);
+    s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+    s2 += __shfl_xor(s2, 4); s2 += __shfl_xor(s2, 8);
+    sr.inv = ln_inv(s2, rk);
+}
+
+__global__ __launch_bounds__(256) void layernorm_sliced_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                               const float *__restrict__ b, half_t *__restrict__ y,
+                                                               float *__restrict__ y32, int M, int K, float rk) {
+    const int t16 = threadIdx.x & 15;
+    int row = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = row < M;
+    if (!live) row = M - 1;  // keep the 16-lane groups whole for the shuffles
+    SlicedRow sr;
+    sliced_row_stats(sr, x + (long)row * K, K, rk, t16);
+    if (!live) return;
+    const int steps = K >> 7, k0 = (t16 >> 2) * 32 * steps + 8 * (t16 & 3);
+#pragma unroll
+    for (int s = 0; s < LN_MAX_STEPS; s++) {
+        if (s < steps) {
+            const int k = k0 + 32 * s;
+            const f32x4 o0 = ln_apply(sr.v[s][0], sr.mean, sr.inv, *reinterpret_cast<const f32x4 *>(w + k), *reinterpret_cast<const f32x4 *>(b + k));
+            const f32x4 o1 = ln_apply(sr.v[s][1], sr.mean, sr.inv, *reinterpret_cast<const f32x4 *>(w + k + 4), *reinterpret_cast<const f32x4 *>(b + k + 4));
+            const half8 h = {(half_t)o0[0], (half_t)o0[1], (half_t)o0[2], (half_t)o0[3], (half_t)o1[0], (half_t)o1[1], (half_t)o1[2], (half_t)o1[3]};
+            *reinterpret_cast<half8 *>(y + (long)row * K + k) = h;
+            if (y32) {
+                *reinterpret_cast<f32x4 *>(y32 + (long)row * K + k) = o0;
+                *reinterpret_cast<f32x4 *>(y32 + (long)row * K + k + 4) = o1;
+            }
+        }
+    }
+}
+
+bool launch_layernorm_sliced(const float *x, const float *w, const float *b, half_t *y, float *y32, int M, int K, hipStream_t st) {
+    if (K % 128 != 0 || K > 128 * LN_MAX_STEPS || M < 1) return false;
+    hipLaunchKernelGGL(layernorm_sliced_kernel, dim3((M + 15) / 16), dim3(256), 0, st, x, w, b, y, y32, M, K, 1.0f / (float)K);
+    return true;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -209,11 +375,32 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(SkinnyParams p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int rows = 16 * NCB, steps = p.K >> 5;
-    for (int c = tid; c < steps * rows * 4; c += 512) {
-        const int q = c & 3, r = (c >> 2) % rows, st = (c >> 2) / rows;
-        const int rr = r < p.R ? r : p.R - 1;
-        const u32x4 v = *reinterpret_cast<const u32x4 *>(p.x + (long)rr * p.ldx + 32 * st + 8 * q);
-        *reinterpret_cast<u32x4 *>(xs + ((long)st * rows + r) * 64 + ((q ^ ((-(r >> 2)) & 3)) << 4)) = v;
+    if (p.ln_x) {
+        // fused final LayerNorm (sliced tree, 16 lanes per row, 32 rows per pass), written as the swizzled fp16 image
+        for (int r = tid >> 4; r < rows; r += 32) {
+            const int t16 = tid & 15, rr = r < p.R ? r : p.R - 1;
+            SlicedRow sr;
+            sliced_row_stats(sr, p.ln_x + (long)rr * p.K, p.K, p.ln_rk, t16);
+            const int nst = p.K >> 7, k0 = (t16 >> 2) * 32 * nst + 8 * (t16 & 3);
+#pragma unroll
+            for (int s = 0; s < LN_MAX_STEPS; s++) {
+                if (s < nst) {
+                    const int k = k0 + 32 * s;
+                    const f32x4 o0 = ln_apply(sr.v[s][0], sr.mean, sr.inv, *reinterpret_cast<const f32x4 *>(p.ln_w + k), *reinterpret_cast<const f32x4 *>(p.ln_b + k));
+                    const f32x4 o1 = ln_apply(sr.v[s][1], sr.mean, sr.inv, *reinterpret_cast<const f32x4 *>(p.ln_w + k + 4), *reinterpret_cast<const f32x4 *>(p.ln_b + k + 4));
+                    const half8 hv = {(half_t)o0[0], (half_t)o0[1], (half_t)o0[2], (half_t)o0[3], (half_t)o1[0], (half_t)o1[1], (half_t)o1[2], (half_t)o1[3]};
+                    const int st = k >> 5, q = (k >> 3) & 3;
+                    *reinterpret_cast<half8 *>(xs + ((long)st * rows + r) * 64 + ((q ^ ((-(r >> 2)) & 3)) << 4)) = hv;
+                }
+            }
+        }
+    } else {
+        for (int c = tid; c < steps * rows * 4; c += 512) {
+            const int q = c & 3, r = (c >> 2) % rows, st = (c >> 2) / rows;
+            const int rr = r < p.R ? r : p.R - 1;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(p.x + (long)rr * p.ldx + 32 * st + 8 * q);
+            *reinterpret_cast<u32x4 *>(xs + ((long)st * rows + r) * 64 + ((q ^ ((-(r >> 2)) & 3)) << 4)) = v;
+        }
     }
     __syncthreads();
     const int tiles = (p.N + 15) >> 4;
@@ -254,9 +441,41 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(SkinnyParams p) {
     }
 }
 
+static bool ln_steps_ok(int K) {
+    const int s = K / 128;
+    return K % 128 == 0 && (s == 1 || s == 2 || s == 3 || s == 4 || s == 6 || s == 8 || s == 10);
+}
+static bool logits_lds_ok(int R, int N, int K) {
+    return (N + 15) / 16 >= 2048 && R <= 32 && (size_t)(K >> 5) * 16 * ((R + 15) / 16) * 64 <= 96 * 1024 && !getenv("NORMA_SK_LOGITS_NT");
+}
+bool skinny_ln_supported(int R, int N, int K) {
+    if (getenv("NORMA_HIP_NO_LN_FUSION")) return false;  // A/B switch
+    if (R > 32) return false;
+    if ((N + 15) / 16 >= 2048) return logits_lds_ok(R, N, K) && K <= 128 * LN_MAX_STEPS && K % 128 == 0;
+    return ln_steps_ok(K);
+}
+
+template <int NCB>
+static void launch_skinny_ln(const SkinnyParams &p, hipStream_t st) {
+    const dim3 grid((p.N + 15) / 16), block(256);
+    switch (p.K / 128) {
+        case 1: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 1>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 2>), grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 3>), grid, block, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 4>), grid, block, 0, st, p); break;
+        case 6: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 6>), grid, block, 0, st, p); break;
+        case 8: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 8>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 10>), grid, block, 0, st, p); break;
+    }
+}
+
 template <int NCB>
 static void launch_skinny_ncb(const SkinnyParams &p, float *slabs, unsigned *tickets, hipStream_t st) {
     const int tiles = (p.N + 15) / 16;
+    if (p.ln_x && tiles < 2048) {  // the caller checked skinny_ln_supported: NCB <= 2
+        if (NCB == 1) launch_skinny_ln<1>(p, st); else launch_skinny_ln<2>(p, st);
+        return;
+    }
     if (tiles >= 2048) {  // the tied-embedding logits: plenty of tiles, stream full rows
         static const int nt_env = getenv("NORMA_SK_LOGITS_NT") ? atoi(getenv("NORMA_SK_LOGITS_NT")) : 0;
         const size_t lds = (size_t)(p.K >> 5) * 16 * NCB * 64;
@@ -293,7 +512,9 @@ static void launch_skinny_ncb(const SkinnyParams &p, float *slabs, unsigned *tic
     else hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 2, 1>), dim3(tiles, ks), dim3(128), 0, st, p, slabs, tickets);
 }
 
-void launch_skinny(const SkinnyParams &p, float *slabs, unsigned *tickets, hipStream_t st) {
+void launch_skinny(const SkinnyParams &p_in, float *slabs, unsigned *tickets, hipStream_t st) {
+    SkinnyParams p = p_in;
+    p.ln_rk = 1.0f / (float)p.K;
     int ncb = (p.R + 15) / 16;
     if (ncb <= 1) launch_skinny_ncb<1>(p, slabs, tickets, st);
     else if (ncb == 2) launch_skinny_ncb<2>(p, slabs, tickets, st);

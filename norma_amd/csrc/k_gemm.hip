@@ -25,16 +25,7 @@
 #define BK 64
 #define TILE_BYTES (BM * BK * 2)  // 16 KiB per operand tile
 
-__device__ __forceinline__ float gelu_tanh_f(float v) {
-    // 0.5 v (1 + tanh(u)) == v / (1 + exp(-2u)),  u = sqrt(2/pi) v (1 + 0.044715 v^2), as 3 full-rate VALU ops + v_exp_f32
-    // + add + v_rcp_f32 + mul: the IEEE division and expf expansions cost ~3x that, and the GELU epilogue of a 256^2 tile
-    // is 128 of these per lane with no MFMA to hide under.  v_exp_f32 / v_rcp_f32 are 1 ulp; the result is then rounded
-    // to fp16 (or added to an O(1) positional embedding).  v -> -inf gives v * rcp(inf) = -0, v -> +inf gives v.
-    const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;  // -2 sqrt(2/pi) log2(e)
-    const float k1 = k0 * 0.044715f;
-    const float m = v * __builtin_fmaf(v * v, k1, k0);
-    return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(m));
-}
+__device__ __forceinline__ float gelu_tanh_f(float v) { return gelu_tanh_fast(v); }
 
 __device__ __forceinline__ const half_t *a_row_ptr(const GemmParams &p, int m) {
     if (m >= p.M) m = p.M - 1;  // clamp: tail rows are loaded but never stored

@@ -72,7 +72,8 @@ struct nh_ctx {
     float *sk_slabs = nullptr;
     unsigned *sk_tickets = nullptr;
     int32_t *d_pos = nullptr;  // device-side decode position (hipGraph replays read it)
-    hipGraphExec_t step_graph = nullptr;
+    hipGraphExec_t step_graph = nullptr;   // one decode step
+    hipGraphExec_t multi_graph = nullptr;  // NH_GRAPH_STEPS consecutive steps (one launch gap instead of NH_GRAPH_STEPS)
     int graph_key[5] = {-1, -1, -1, -1, -1};
     std::vector<int32_t> seq_lang;  // per-sequence language tokens (LanguageState::Detect), empty = tk.lang for all
     int32_t *d_lang_tokens = nullptr, *d_lang_out = nullptr;
@@ -154,6 +155,7 @@ extern "C" void nh_destroy(nh_ctx *ctx) {
     if (ctx->sd) hipStreamSynchronize(ctx->sd);
     for (void *p : ctx->allocs) hipFree(p);
     if (ctx->step_graph) hipGraphExecDestroy(ctx->step_graph);
+    if (ctx->multi_graph) hipGraphExecDestroy(ctx->multi_graph);
     if (ctx->h_done) hipHostFree(ctx->h_done);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     for (auto &e : ctx->gemm_ev) hipEventDestroy(e);
@@ -621,38 +623,68 @@ extern "C" int nh_encoder_output(nh_ctx *ctx, int b, float *out) {
 }
 
 // ---- decoder ---------------------------------------------------------------------------------------------
+#define NH_GRAPH_STEPS 8
 static void skinny(nh_ctx *ctx, const half_t *x, long ldx, const LinW &W, int R, int N, int K, int epi, void *o0, void *o1,
-                   void *o2, long ldo, int t0, int ctxlen, const int32_t *pos_ptr = nullptr) {
+                   void *o2, long ldo, int t0, int ctxlen, const int32_t *pos_ptr = nullptr, const float *ln_x = nullptr,
+                   const float *ln_w = nullptr, const float *ln_b = nullptr) {
     SkinnyParams p{};
-    p.pos_ptr = pos_ptr;
+    p.pos_ptr = pos_ptr; p.ln_x = ln_x; p.ln_w = ln_w; p.ln_b = ln_b;
     p.x = x; p.ldx = ldx; p.W = W.w; p.bias = W.b; p.R = R; p.N = N; p.K = K; p.epi = epi;
     p.out[0] = o0; p.out[1] = o1; p.out[2] = o2; p.ldo = ldo; p.d = ctx->c.d_model; p.t0 = t0; p.Tn = 1; p.ctx = ctxlen;
     launch_skinny(p, ctx->sk_slabs, ctx->sk_tickets, ctx->sd);
 }
 
-// one decoder position for the whole batch: consumes tokens[b][pos], leaves LN(x) in dxn (fp16) / dy32 (f32).
+// every decoder LayerNorm uses the "sliced" summation tree (nh_kernels.h) when the width allows, so that the fused and
+// the stand-alone forms, and every batch size, give bit-identical rows
+static void dec_layernorm(nh_ctx *ctx, const LnW &ln, half_t *y, float *y32, int R, int K) {
+    if (!launch_layernorm_sliced(ctx->dx, ln.w, ln.b, y, y32, R, K, ctx->sd)) launch_layernorm(ctx->dx, ln.w, ln.b, y, y32, R, K, ctx->sd);
+}
+
+// LayerNorm + projection of one decode step: fused into the skinny GEMM when the shape allows (the separate
+// LayerNorm launch is pure latency at B rows), otherwise LayerNorm into dxn first
+static void ln_skinny(nh_ctx *ctx, const LnW &ln, const LinW &W, int R, int N, int K, int epi, void *o0, void *o1, void *o2,
+                      long ldo, int t0, int ctxlen, const int32_t *pos_ptr) {
+    if (skinny_ln_supported(R, N, K)) {
+        skinny(ctx, nullptr, K, W, R, N, K, epi, o0, o1, o2, ldo, t0, ctxlen, pos_ptr, ctx->dx, ln.w, ln.b);
+    } else {
+        dec_layernorm(ctx, ln, ctx->dxn, nullptr, R, K);
+        skinny(ctx, ctx->dxn, K, W, R, N, K, epi, o0, o1, o2, ldo, t0, ctxlen, pos_ptr);
+    }
+}
+
+// one decoder position for the whole batch: consumes tokens[b][pos], leaves the residual stream in dx.
+// final_ln: also LN(dx) -> dxn (fp16) / dy32 (f32) (the teacher-forced view; the step path fuses it into the logits).
 // pos_ptr != nullptr: the position comes from device memory (the step is being captured into a hipGraph).
-static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr) {
+static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr, bool final_ln = true) {
     const int d = ctx->c.d_model, B = ctx->cur_batch, H = ctx->c.decoder_attention_heads, C = ctx->c.max_target_positions;
     launch_embed(ctx->ds.tokens, C, ctx->tok_emb, ctx->dec_pos, ctx->dx, B, 1, pos, pos_ptr, d, ctx->sd);
     for (auto &L : ctx->dec) {
-        launch_layernorm(ctx->dx, L.ln1.w, L.ln1.b, ctx->dxn, nullptr, B, d, ctx->sd);
-        skinny(ctx, ctx->dxn, d, L.qkv, B, 3 * d, d, SK_QKV, ctx->dq, L.sk, L.sv, d, pos, C, pos_ptr);
+        ln_skinny(ctx, L.ln1, L.qkv, B, 3 * d, d, SK_QKV, ctx->dq, L.sk, L.sv, d, pos, C, pos_ptr);
         launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos_ptr, ctx->sd);
         skinny(ctx, ctx->datt, d, L.o, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
-        launch_layernorm(ctx->dx, L.ln2.w, L.ln2.b, ctx->dxn, nullptr, B, d, ctx->sd);
-        skinny(ctx, ctx->dxn, d, L.cq, B, d, d, SK_F16, ctx->dq, nullptr, nullptr, d, 0, C);
+        ln_skinny(ctx, L.ln2, L.cq, B, d, d, SK_F16, ctx->dq, nullptr, nullptr, d, 0, C, nullptr);
         launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, nullptr, ctx->sd);
         skinny(ctx, ctx->datt, d, L.co, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
-        launch_layernorm(ctx->dx, L.ln3.w, L.ln3.b, ctx->dxn, nullptr, B, d, ctx->sd);
-        skinny(ctx, ctx->dxn, d, L.fc1, B, 4 * d, d, SK_GELU_F16, ctx->dhid, nullptr, nullptr, 4 * d, 0, C);
+        ln_skinny(ctx, L.ln3, L.fc1, B, 4 * d, d, SK_GELU_F16, ctx->dhid, nullptr, nullptr, 4 * d, 0, C, nullptr);
         skinny(ctx, ctx->dhid, 4 * d, L.fc2, B, d, 4 * d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
     }
-    launch_layernorm(ctx->dx, ctx->dec_ln.w, ctx->dec_ln.b, ctx->dxn, ctx->dy32, B, d, ctx->sd);
+    if (final_ln) dec_layernorm(ctx, ctx->dec_ln, ctx->dxn, ctx->dy32, B, d);
+}
+
+// TextDecoder::final_linear on LN(dx) of the R rows of the last decoder_step(..., final_ln = false)
+static void logits_from_dx(nh_ctx *ctx, int R) {
+    LinW E; E.w = ctx->tok_emb; E.b = nullptr;  // tied embedding, no bias (final_linear)
+    const int d = ctx->c.d_model, V = ctx->c.vocab_size;
+    if (skinny_ln_supported(R, V, d)) {
+        skinny(ctx, nullptr, d, E, R, V, d, SK_F32, ctx->logits, nullptr, nullptr, ctx->VP, 0, 0, nullptr, ctx->dx, ctx->dec_ln.w, ctx->dec_ln.b);
+    } else {
+        dec_layernorm(ctx, ctx->dec_ln, ctx->dxn, nullptr, R, d);
+        skinny(ctx, ctx->dxn, d, E, R, V, d, SK_F32, ctx->logits, nullptr, nullptr, ctx->VP, 0, 0);
+    }
 }
 
 static void logits_from_dxn(nh_ctx *ctx, int R) {
-    LinW E; E.w = ctx->tok_emb; E.b = nullptr;  // tied embedding, no bias (final_linear)
+    LinW E; E.w = ctx->tok_emb; E.b = nullptr;
     skinny(ctx, ctx->dxn, ctx->c.d_model, E, R, ctx->c.vocab_size, ctx->c.d_model, SK_F32, ctx->logits, nullptr, nullptr,
            ctx->VP, 0, 0);
 }
@@ -697,36 +729,48 @@ extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_resu
         }
     }
     // Generation phase: one token per step from pos = P-1 on.  The length cap (model.rs:367) forces eot once
-    // pos + 2 >= cap, so pos never exceeds cap - 2.  The 26-launch step is captured once into a hipGraph that
+    // pos + 2 >= cap, so pos never exceeds cap - 2.  The ~20-launch step is captured (once, and 8 steps back to back) into hipGraphs that
     // reads the position from device memory (the eager loop is host-launch-bound at ~5 us per tiny kernel).
     static const bool no_graph = getenv("NORMA_HIP_NO_GRAPH") != nullptr;
     const int key[5] = {B, ctx->S, max_new_tokens, P, 1};
     if (!no_graph && memcmp(key, ctx->graph_key, sizeof(key)) != 0) {
         if (ctx->step_graph) { hipGraphExecDestroy(ctx->step_graph); ctx->step_graph = nullptr; }
-        hipGraph_t g = nullptr;
-        HIPCHK(hipStreamBeginCapture(ctx->sd, hipStreamCaptureModeThreadLocal));
-        decoder_step(ctx, 0, ctx->d_pos);
-        logits_from_dxn(ctx, B);
-        launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, ctx->d_pos, ctx->sd);
-        HIPCHK(hipStreamEndCapture(ctx->sd, &g));
-        hipError_t ge = hipGraphInstantiate(&ctx->step_graph, g, nullptr, nullptr, 0);
-        hipGraphDestroy(g);
-        if (ge != hipSuccess) return ctx->fail(NH_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge));
+        if (ctx->multi_graph) { hipGraphExecDestroy(ctx->multi_graph); ctx->multi_graph = nullptr; }
+        for (int which = 0; which < 2; which++) {
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(ctx->sd, hipStreamCaptureModeThreadLocal));
+            for (int i = 0; i < (which ? NH_GRAPH_STEPS : 1); i++) {  // every step reads and advances the device-side position
+                decoder_step(ctx, 0, ctx->d_pos, false);
+                logits_from_dx(ctx, B);
+                launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, ctx->d_pos, ctx->sd);
+            }
+            HIPCHK(hipStreamEndCapture(ctx->sd, &g));
+            hipError_t ge = hipGraphInstantiate(which ? &ctx->multi_graph : &ctx->step_graph, g, nullptr, nullptr, 0);
+            hipGraphDestroy(g);
+            if (ge != hipSuccess) return ctx->fail(NH_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge));
+        }
         memcpy(ctx->graph_key, key, sizeof(key));
     }
     const int32_t first_pos = P - 1;
     ctx->h_done[100] = first_pos;
     HIPCHK(hipMemcpyAsync(ctx->d_pos, &ctx->h_done[100], sizeof(int32_t), hipMemcpyHostToDevice, ctx->sd));
-    for (int pos = first_pos; pos <= cap - 2; pos++) {
+    // positions first_pos .. cap - 2; the host looks at the done flags every 16 steps (and after the last one)
+    for (int pos = first_pos; pos <= cap - 2;) {
+        int n = 1;
         if (no_graph) {
-            decoder_step(ctx, pos);
-            logits_from_dxn(ctx, B);
+            decoder_step(ctx, pos, nullptr, false);
+            logits_from_dx(ctx, B);
             launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, nullptr, ctx->sd);
+        } else if (pos + NH_GRAPH_STEPS - 1 <= cap - 2) {
+            HIPCHK(hipGraphLaunch(ctx->multi_graph, ctx->sd));
+            n = NH_GRAPH_STEPS;
         } else {
             HIPCHK(hipGraphLaunch(ctx->step_graph, ctx->sd));
         }
-        steps++;
-        if (((pos - first_pos) & 15) == 15 || pos == cap - 2) {
+        steps += n;
+        const int before = pos - first_pos;
+        pos += n;
+        if ((before >> 4) != ((pos - first_pos) >> 4) || pos > cap - 2) {
             HIPCHK(hipMemcpyAsync(ctx->h_done, ctx->ds.done, B * 4, hipMemcpyDeviceToHost, ctx->sd));
             HIPCHK(hipStreamSynchronize(ctx->sd));
             bool all = true;

@@ -55,7 +55,75 @@ struct SkinnyParams {
     // SK_QKV: row r = b*Tn + i  (Tn new positions per sequence); cache row = (b*ctx + t0 + i)
     int d, t0, Tn, ctx;
     const int32_t *pos_ptr;  // when set, t0 is read from device memory (hipGraph replay of the decode step)
+    // LayerNorm fused into the activation load (skinny_ln_supported): x is ignored, the activations are
+    // LN(ln_x[r][0..K)) * ln_w + ln_b (eps 1e-5, two-pass f32 statistics), rounded to fp16 like layernorm_kernel does
+    const float *ln_x, *ln_w, *ln_b;
+    float ln_rk;  // 1.0f / K, filled in by launch_skinny
 };
+// true when launch_skinny can take its activations through the fused LayerNorm for this shape
+bool skinny_ln_supported(int R, int N, int K);
+
+// ---- the decoder's LayerNorm arithmetic ("sliced") ------------------------------------------------
+// One fixed summation tree for every LayerNorm of a decode step, whether it runs fused inside a skinny GEMM, in the
+// logits kernel's staging pass or as the stand-alone kernel (rows > 32, teacher-forced views): a row of K = 128 STEPS
+// values is cut into 4 slices of 32 STEPS; in slice w lane fq sums the 8 values at 32 s + 8 fq (s ascending), the four
+// lanes meet as (l0 + l1) + (l2 + l3), the slices as (p0 + p1) + (p2 + p3).  Results are therefore bit-identical across
+// batch sizes and across the fused / unfused paths.
+#ifdef __HIPCC__
+// tanh-GELU (candle's Activation::Gelu is the tanh form): 0.5 v (1 + tanh(u)) == v / (1 + exp(-2u)),
+// u = sqrt(2/pi) v (1 + 0.044715 v^2), as 3 full-rate VALU ops + v_exp_f32 + add + v_rcp_f32 + mul.  The IEEE division
+// and expf expansions cost ~3x that (the GELU epilogue of a 256^2 GEMM tile is 128 of these per lane with no MFMA to
+// hide under), and the library expf carries fast-math flags that let the compiler fold it differently into different
+// kernels; this form is explicit, so every kernel gives the same bits.  v_exp_f32 / v_rcp_f32 are 1 ulp; the result is
+// then rounded to fp16 (or added to an O(1) positional embedding).  v -> -inf gives v * rcp(inf) = -0, v -> +inf gives v.
+// (hipcc's default -ffp-contract=fast lets the backend fuse any mul + add it meets after inlining, differently from
+// kernel to kernel; the helpers below switch that off and spell their FMAs out, so they round the same everywhere.)
+__device__ __forceinline__ float gelu_tanh_fast(float v) {
+#pragma clang fp contract(off)
+    const float k0 = -2.0f * 0.7978845608028654f * 1.4426950408889634f;  // -2 sqrt(2/pi) log2(e)
+    const float k1 = k0 * 0.044715f;
+    const float m = v * __builtin_fmaf(v * v, k1, k0);
+    float r = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(m));
+    asm("" : "+v"(r));  // keep the f32 product: no v_fma_mix*_f16 fusion with a following fp16 conversion (see ln_apply)
+    return r;
+}
+__device__ __forceinline__ float ln_sum8(float acc, const f32x4 &a, const f32x4 &b) {
+#pragma clang fp contract(off)
+    acc += (a[0] + a[1]) + (a[2] + a[3]);
+    acc += (b[0] + b[1]) + (b[2] + b[3]);
+    return acc;
+}
+__device__ __forceinline__ float ln_sq8(float acc, const f32x4 &a, const f32x4 &b, float mean) {
+#pragma clang fp contract(off)
+    const f32x4 t = a - mean, u = b - mean;
+    acc += __builtin_fmaf(t[1], t[1], t[0] * t[0]) + __builtin_fmaf(t[3], t[3], t[2] * t[2]);
+    acc += __builtin_fmaf(u[1], u[1], u[0] * u[0]) + __builtin_fmaf(u[3], u[3], u[2] * u[2]);
+    return acc;
+}
+// rk = 1.0f / K, computed by the host (or at compile time): hipcc turns a division by a compile-time constant into a
+// multiplication by its reciprocal but divides at run time, which rounds differently
+__device__ __forceinline__ float ln_mean(float sum, float rk) {
+#pragma clang fp contract(off)
+    return sum * rk;
+}
+__device__ __forceinline__ float ln_inv(float sumsq, float rk) {
+#pragma clang fp contract(off)
+    const float var = sumsq * rk;
+    return 1.0f / sqrtf(var + 1e-5f);
+}
+__device__ __forceinline__ f32x4 ln_apply(const f32x4 &x, float mean, float inv, const f32x4 &g, const f32x4 &b) {
+#pragma clang fp contract(off)
+    const f32x4 t = (x - mean) * inv;
+    f32x4 o = {__builtin_fmaf(t[0], g[0], b[0]), __builtin_fmaf(t[1], g[1], b[1]), __builtin_fmaf(t[2], g[2], b[2]),
+               __builtin_fmaf(t[3], g[3], b[3])};
+    // the f32 value has to exist: otherwise hipcc folds the FMA and the fp16 conversion that follows into v_fma_mixlo_f16
+    // (ONE rounding, to fp16) in some kernels and keeps v_cvt_pk_f16_f32 (two roundings) in others -- different bits at ties
+    asm("" : "+v"(o));
+    return o;
+}
+#endif
+// stand-alone kernel with that arithmetic (K % 128 == 0, K <= 1280); returns false when the shape is not covered
+bool launch_layernorm_sliced(const float *x, const float *w, const float *b, half_t *y, float *y32, int M, int K, hipStream_t st);
 #define SKINNY_MAX_TILES 512
 // slabs: f32 [SKINNY_MAX_TILES][8][64][16] scratch for cross-workgroup split-K (nullptr: never split across
 // workgroups); tickets: u32 [SKINNY_MAX_TILES], zero-initialised, self-resetting

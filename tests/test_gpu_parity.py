@@ -342,3 +342,30 @@ def test_clip_shorter_than_one_hop_uses_the_1500_frame_path():
     xa = om.encoder_forward(O.pcm_to_mel(full, filt))
     assert np.abs(hm.encoder_output(0) - xa).max() <= 2e-3
     hm.close(); om.close()
+
+
+@pytest.mark.gpu
+def test_fused_layernorm_decode_is_bit_identical_to_the_unfused_path():
+    """The decode step fuses every LayerNorm into the projection that consumes it (skinny_ln_kernel, the logits staging
+    pass).  NORMA_HIP_NO_LN_FUSION=1 runs the stand-alone sliced LayerNorm + plain GEMM instead; both must give the same
+    tokens and bit-identical log-probabilities (one summation tree, one rounding sequence: nh_kernels.h)."""
+    import subprocess, sys, json
+    prog = (
+        "import sys, json; sys.path.insert(0, 'tests'); sys.path.insert(0, '.');\n"
+        "import common; from norma_amd import config, synth\n"
+        "name = 'test-d256-mel128'; cfg = config.preset(name); tk = common.tokens_for(name)\n"
+        "script = common.transcript_script(tk, n_segments=3, words_per_segment=6, seed=21)\n"
+        "hm = common.build_hip(cfg, tk, seed=1, overrides=common.scripted_overrides(cfg, tk, script), max_batch=3)\n"
+        "hm.logmel([synth.synth_pcm(k, 480000) for k in (17, 4, 9)]); hm.encode(); r = hm.decode_greedy()\n"
+        "print(json.dumps([[x['tokens'], x['avg_logprob'].hex(), x['no_speech_prob'].hex()] for x in r]))\n")
+    outs = []
+    for fuse in (True, False):
+        env = dict(os.environ)
+        env.pop("NORMA_HIP_NO_LN_FUSION", None)
+        if not fuse:
+            env["NORMA_HIP_NO_LN_FUSION"] = "1"
+        p = subprocess.run([sys.executable, "-c", prog], cwd=common.ROOT, env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]
+    assert len(outs[0][0][0]) > 10

@@ -10,7 +10,7 @@ import sys
 
 
 def load(d, cname):
-    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    f = (glob.glob(d + "/*_counter_collection.csv") + glob.glob(d + "/*/*_counter_collection.csv"))[0]
     out = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == cname:
