@@ -24,6 +24,7 @@
  *   nh_encoder_output, nh_decoder_forward, nh_final_linear, nh_apply_rules
  *                                 fine-grained views of the same state for layer-level parity:
  *                                 Type::decoder_forward / decoder_final_linear (model.rs:466-483)
+ *   nh_decode_sampled             Model::decode at t > 0 (model.rs:340-348) under the seeded sampling contract below
  *   nh_detect_language            Model::detect_language (model.rs:194-210)
  *   nh_reset                      Type::reset_kv_cache (model.rs:485-490)
  */
@@ -114,6 +115,19 @@ int nh_encode(nh_ctx *ctx);
 /* Greedy decode of all `batch` sequences.  out_tokens: host i32 [batch][max_target_positions],
  * results: [batch].  max_new_tokens <= 0: reference behaviour (cap at max_target_positions - 1). */
 int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *results, int max_new_tokens);
+/* Model::decode at t > 0 (model.rs:340-348): every token is SAMPLED from softmax(q / t), q = the rule-masked
+ * probabilities.  The reference draws with rand::WeightedIndex from an entropy-seeded StdRng (model.rs:30), so only its
+ * distribution can be reproduced; this build fixes a seeded SAMPLING CONTRACT (the C oracle implements the same, bit for bit):
+ *   weights  w_i = sexp((q_i - max q) * (1.0f / t)), sexp = exp from IEEE f32 operations only (Cephes polynomial),
+ *            masked entries (-inf) weigh 0; this is softmax(q / t) up to the normalisation WeightedIndex ignores;
+ *   uniform  u = (philox4x32-10(key = {seed lo, seed hi}, counter = {step, clip, attempt, 0x6e6f726d})[0] >> 8) * 2^-24,
+ *            step = tokens in the sequence so far, clip = clip0 + index in the batch, attempt = index into
+ *            TEMPERATURES (decode_with_fallback, model.rs:175);
+ *   choice   the first token whose cumulative weight exceeds u * total (WeightedIndex::sample's partition_point),
+ *            cumulated in f64 over 1024 chunks of ceil(V / 1024) consecutive tokens, then inside the chunk;
+ *   all masked: eot is pushed and the sequence stops (model.rs:343-346).  Log-prob bookkeeping as for t = 0. */
+int nh_decode_sampled(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *results, int max_new_tokens,
+                      float temperature, uint64_t seed, uint32_t clip0, uint32_t attempt);
 /* Model::detect_language (model.rs:194-210) for every clip of the batch: one decoder step on [sot], softmax over the
  * n language-token logits (lang_tokens in `Language::iter()` order, multilingual.rs:395-398), first maximum.
  * out_lang: host i32 [batch]; out_probs: host f32 [batch][n] or NULL.  The detected tokens become the per-sequence
@@ -143,6 +157,10 @@ int nh_final_linear(nh_ctx *ctx, const float *x, int rows, float *logits_out);
  * (< 0: first generated token).  Returns the masked probabilities (model.rs:333-338). */
 int nh_apply_rules(nh_ctx *ctx, const float *probs, const int32_t *tokens, int n_tokens,
                    int last_timestamp, float *masked_out, int32_t *argmax_out);
+
+/* The sampler alone: rules + one draw on a soft-maxed probability vector (token_out = -1: everything masked). */
+int nh_sample_rules(nh_ctx *ctx, const float *probs, const int32_t *tokens, int n_tokens, int last_timestamp,
+                    float temperature, uint64_t seed, uint32_t clip, uint32_t attempt, int32_t *token_out);
 
 /* ---- instrumentation --------------------------------------------------------------------------- */
 /* Milliseconds (HIP events on the context's stream) spent in the phases of the last

@@ -60,6 +60,10 @@ nm_model *nm_definition_blocking_try_to_model_from_dir(const nm_definition *d, c
  * (nm_definition_blocking_try_to_model_from_dir enables it itself when `language` is NULL or "".) */
 void nm_model_enable_language_detection(nm_model *m, const int32_t *lang_tokens, int n);
 int nm_model_language_token(const nm_model *m); /* current language token, -1 = not detected yet */
+/* decode_with_fallback's sampled attempts at t = 0.2 .. 1.0 (model.rs:175-188).  Off by default: the t = 0 result is
+ * returned and nm_model_last_result reports needed_fallback.  On: the reference's loop, drawing under the seeded
+ * sampling contract of norma_hip.h (the reference seeds from entropy, so draws cannot match, only their distribution). */
+void nm_model_set_temperature_fallback(nm_model *m, int enable, uint64_t seed);
 /* text of the last nm_model_transcribe call (empty without a tokenizer); returns its length */
 int nm_model_last_text(const nm_model *m, char *buf, int cap);
 void nm_model_free(nm_model *m);

@@ -688,31 +688,34 @@ __device__ __forceinline__ float masked_value(float p, int i, int rule, const ui
     return m ? p + (-INFINITY) : p;
 }
 
-// shared by the decode step and the parity helper.  probs(i) gives the soft-maxed probability.
+// which of the four mask chains of model.rs:331-338 / :245-277 applies.  probs(i) gives the soft-maxed probability.
+template <typename ProbFn>
+__device__ __forceinline__ int rules_decide(ProbFn probs, int V, const int32_t *tokens, int n, int have_last,
+                                            const uint8_t *sup, const RuleTokens &tk, BlockRed &sm) {
+    if (!have_last) return RULE_FIRST;
+    int l = tokens[n - 1];
+    if (l > tk.no_timestamps) {
+        int sl = n >= 2 ? tokens[n - 2] : -1;
+        return (n >= 2 && sl >= tk.eot) ? RULE_SUP_TS : RULE_NON_TS;
+    }
+    float ps = 0.f, pm = -INFINITY;  // model.rs:263-270 on the suppress-masked probabilities
+    for (int i = threadIdx.x; i < V; i += blockDim.x) {
+        float p = probs(i);
+        float pv = sup[i] ? p + (-INFINITY) : p;
+        if (i > tk.no_timestamps) ps += pv;
+        else if (i < tk.no_timestamps) pm = fmaxf(pm, pv);
+    }
+    float sum_ts = block_sum(ps, sm);
+    float max_text = block_max(pm, sm);
+    return (sum_ts >= max_text) ? RULE_NON_TS : RULE_PAST;
+}
+
+// shared by the parity helper and the sampled step: rules, then the greedy arg max
 template <typename ProbFn>
 __device__ __forceinline__ void rules_argmax(ProbFn probs, int V, const int32_t *tokens, int n, int have_last,
                                              int last_ts, const uint8_t *sup, const RuleTokens &tk, BlockRed &sm,
                                              int &rule_out, int &next_out) {
-    int rule;
-    if (!have_last) rule = RULE_FIRST;
-    else {
-        int l = tokens[n - 1];
-        if (l > tk.no_timestamps) {
-            int sl = n >= 2 ? tokens[n - 2] : -1;
-            rule = (n >= 2 && sl >= tk.eot) ? RULE_SUP_TS : RULE_NON_TS;
-        } else {
-            float ps = 0.f, pm = -INFINITY;  // model.rs:263-270 on the suppress-masked probabilities
-            for (int i = threadIdx.x; i < V; i += blockDim.x) {
-                float p = probs(i);
-                float pv = sup[i] ? p + (-INFINITY) : p;
-                if (i > tk.no_timestamps) ps += pv;
-                else if (i < tk.no_timestamps) pm = fmaxf(pm, pv);
-            }
-            float sum_ts = block_sum(ps, sm);
-            float max_text = block_max(pm, sm);
-            rule = (sum_ts >= max_text) ? RULE_NON_TS : RULE_PAST;
-        }
-    }
+    const int rule = rules_decide(probs, V, tokens, n, have_last, sup, tk, sm);
     int bk = INT_MIN, bi = -1;
     for (int i = threadIdx.x; i < V; i += blockDim.x) {
         float v = masked_value(probs(i), i, rule, sup, tk, last_ts);
@@ -722,6 +725,149 @@ __device__ __forceinline__ void rules_argmax(ProbFn probs, int V, const int32_t 
     int ok, oi;
     block_argmax(bk, bi, sm, ok, oi);
     rule_out = rule; next_out = oi;
+}
+
+// ---- sampled decoding, t > 0 (model.rs:340-348) ------------------------------------------------------------
+// The reference draws from rand's WeightedIndex over softmax(q / t), q = the rule-masked PROBABILITIES, with an
+// entropy-seeded StdRng, so only its distribution can be matched.  The seeded contract (include/norma_hip.h):
+//   w_i = sexp((q_i - max q) * inv_t)        sexp: exp from IEEE f32 operations only, identical in the C oracle
+//   u   = (philox4x32-10(key = seed, ctr = {step, clip, attempt, "norm"})[0] >> 8) * 2^-24
+//   token = first j whose cumulative weight exceeds u * total, cumulated in f64 over 1024 chunks of ceil(V / 1024)
+// One 1024-thread workgroup per sequence; thread c owns chunk c, thread 0 then walks the chunk sums.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1,
+                                              unsigned &o0) {
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o0 = c0;
+}
+
+__device__ __forceinline__ float sexp(float y) {
+#pragma clang fp contract(off)
+    if (!(y >= -87.0f)) return 0.0f;  // also -inf and NaN: a masked token has weight 0
+    const float kf = floorf(__builtin_fmaf(y, 1.44269504088896341f, 0.5f));
+    float r = __builtin_fmaf(kf, -0.693359375f, y);
+    r = __builtin_fmaf(kf, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    const float z = r * r;
+    const float res = __builtin_fmaf(p, z, r) + 1.0f;
+    return res * __uint_as_float((unsigned)((int)kf + 127) << 23);
+}
+
+struct SampleShared { BlockRed red; double chunk[1024]; int result; float qres; };
+
+// q(i): rule-masked probability.  Returns (all threads) the sampled token or -1 when everything is masked; qout = q(token).
+template <typename QFn>
+__device__ __forceinline__ int sample_masked(QFn q, int V, float inv_t, unsigned long long seed, unsigned clip, unsigned step,
+                                             unsigned attempt, SampleShared &sh, float &qout) {
+#pragma clang fp contract(off)
+    const int tid = threadIdx.x;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, q(i));
+    const float qmax = block_max(mx, sh.red);
+    if (!(qmax > -INFINITY)) { qout = 0.f; return -1; }
+    const int CH = (V + 1023) / 1024;
+    double sc = 0.0;
+    for (int i = tid * CH; i < (tid + 1) * CH && i < V; i++) sc += (double)sexp((q(i) - qmax) * inv_t);
+    sh.chunk[tid] = sc;
+    __syncthreads();
+    if (tid == 0) {
+        double total = 0.0;
+        for (int c = 0; c < 1024; c++) total += sh.chunk[c];
+        unsigned r0;
+        philox4x32_10(step, clip, attempt, 0x6e6f726du, (unsigned)seed, (unsigned)(seed >> 32), r0);
+        const float u = (float)(r0 >> 8) * (1.0f / 16777216.0f);
+        const double x = (double)u * total;
+        double run = 0.0;
+        int c = 0;
+        for (; c < 1023; c++) { if (run + sh.chunk[c] > x) break; run += sh.chunk[c]; }
+        int res = -1, last_pos = -1;
+        for (int i = c * CH; i < V; i++) {  // walks on past the chunk only if rounding left x >= the chunk's end
+            const float w = sexp((q(i) - qmax) * inv_t);
+            if (w > 0.0f) last_pos = i;
+            run += (double)w;
+            if (run > x) { res = i; break; }
+        }
+        if (res < 0) res = last_pos;
+        sh.result = res; sh.qres = q(res);
+    }
+    __syncthreads();
+    qout = sh.qres;
+    return sh.result;
+}
+
+// one generated token per sequence at temperature 1 / inv_t: softmax, rules, sampling, the bookkeeping of
+// model.rs:359-370.  Same state as logit_step_kernel (which stays the t = 0 path and the no-speech probe).
+__global__ __launch_bounds__(1024) void sample_step_kernel(const float *__restrict__ logits, int V, int ldl, DecodeState s,
+                                                           RuleTokens tk, int ctx, int cap, int max_new, int prompt_len,
+                                                           float inv_t, unsigned long long seed, unsigned clip0, unsigned attempt) {
+    __shared__ SampleShared sh;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (s.done[b]) return;
+    const float *lg = logits + (long)b * ldl;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += 1024) mx = fmaxf(mx, lg[i]);
+    const float m = block_max(mx, sh.red);
+    float se = 0.f;
+    for (int i = tid; i < V; i += 1024) se += expf(lg[i] - m);
+    se = block_sum(se, sh.red);
+    auto probs = [&](int i) { return expf(lg[i] - m) / se; };  // model.rs:331
+    int32_t *toks = s.tokens + (long)b * ctx;
+    const int n = s.n_tokens[b], have_last = s.have_last[b], last_ts = s.last_ts[b];
+    const int rule = rules_decide(probs, V, toks, n, have_last, s.suppress, tk, sh.red);
+    auto q = [&](int i) { return masked_value(probs(i), i, rule, s.suppress, tk, last_ts); };
+    float qv;
+    const int next = sample_masked(q, V, inv_t, seed, clip0 + b, (unsigned)n, attempt, sh, qv);
+    if (tid != 0) return;
+    int nn = n, fin = 0;
+    if (next < 0) { toks[nn++] = tk.eot; fin = 1; }                // :343-346 all NaN: push eot, stop (no log-prob)
+    else {
+        if (next > tk.no_timestamps) { s.last_ts[b] = next; s.have_last[b] = 1; }  // :359-361
+        toks[nn++] = next;
+        s.sum_logprob[b] += log((double)qv);                       // :364-365
+        if (nn >= cap) { toks[nn++] = tk.eot; fin = 1; }           // :367-370
+        else if (next == tk.eot) fin = 1;                          // :317
+        else if (max_new > 0 && nn - prompt_len >= max_new) { toks[nn++] = tk.eot; fin = 1; }
+    }
+    s.n_tokens[b] = nn;
+    if (fin) s.done[b] = 1;
+}
+
+void launch_sample_step(const float *logits, int V, DecodeState s, RuleTokens tk, int B, int ctx, int cap, int max_new,
+                        int prompt_len, float inv_t, unsigned long long seed, unsigned clip0, unsigned attempt, hipStream_t st) {
+    const int ldl = (V + 63) & ~63;
+    hipLaunchKernelGGL(sample_step_kernel, dim3(B), dim3(1024), 0, st, logits, V, ldl, s, tk, ctx, cap, max_new, prompt_len,
+                       inv_t, seed, clip0, attempt);
+}
+
+// parity view of the sampler: rules + one draw on an already soft-maxed probability vector
+__global__ __launch_bounds__(1024) void sample_rules_kernel(const float *__restrict__ probs_in, int32_t *token_out,
+                                                            const int32_t *tokens, int n, int last_ts, const uint8_t *sup,
+                                                            RuleTokens tk, int V, float inv_t, unsigned long long seed,
+                                                            unsigned clip, unsigned attempt) {
+    __shared__ SampleShared sh;
+    auto probs = [&](int i) { return probs_in[i]; };
+    const int rule = rules_decide(probs, V, tokens, n, last_ts >= 0, sup, tk, sh.red);
+    auto q = [&](int i) { return masked_value(probs_in[i], i, rule, sup, tk, last_ts); };
+    float qv;
+    const int next = sample_masked(q, V, inv_t, seed, clip, (unsigned)n, attempt, sh, qv);
+    if (threadIdx.x == 0) *token_out = next;
+}
+
+void launch_sample_rules(const float *probs_in, int32_t *token_out, const int32_t *tokens, int n_tokens, int last_ts,
+                         const uint8_t *suppress, RuleTokens tk, int V, float inv_t, unsigned long long seed, unsigned clip,
+                         unsigned attempt, hipStream_t st) {
+    hipLaunchKernelGGL(sample_rules_kernel, dim3(1), dim3(1024), 0, st, probs_in, token_out, tokens, n_tokens, last_ts, suppress,
+                       tk, V, inv_t, seed, clip, attempt);
 }
 
 // ---- the fused decode-step version: ONE sweep over the logits, LSPLIT workgroups per sequence -----------

@@ -689,10 +689,13 @@ static void logits_from_dxn(nh_ctx *ctx, int R) {
            ctx->VP, 0, 0);
 }
 
-extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *results, int max_new_tokens) {
-    if (!ctx || !out_tokens || !results) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_decode_greedy: bad arguments") : NH_ERR_INVALID;
-    if (!ctx->have_enc) return ctx->fail(NH_ERR_STATE, "nh_decode_greedy: call nh_encode first");
-    if (!ctx->have_tokens) return ctx->fail(NH_ERR_STATE, "nh_decode_greedy: call nh_set_tokens first");
+// Model::decode (model.rs:279-389) for the whole batch.  inv_t == 0: t = 0, greedy (hipGraph replay); inv_t > 0: every
+// token is sampled at temperature 1 / inv_t under the seeded contract (eager launches: the fallback path is rare).
+static int decode_impl(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *results, int max_new_tokens, float inv_t,
+                       unsigned long long seed, unsigned clip0, unsigned attempt) {
+    if (!ctx || !out_tokens || !results) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_decode: bad arguments") : NH_ERR_INVALID;
+    if (!ctx->have_enc) return ctx->fail(NH_ERR_STATE, "nh_decode: call nh_encode first");
+    if (!ctx->have_tokens) return ctx->fail(NH_ERR_STATE, "nh_decode: call nh_set_tokens first");
     hipSetDevice(ctx->dev);
     const int B = ctx->cur_batch, C = ctx->c.max_target_positions, cap = C - 1, V = ctx->c.vocab_size;
     // model.rs:285-289: prompt = [sot, lang?, task]
@@ -731,7 +734,8 @@ extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_resu
     // Generation phase: one token per step from pos = P-1 on.  The length cap (model.rs:367) forces eot once
     // pos + 2 >= cap, so pos never exceeds cap - 2.  The ~20-launch step is captured (once, and 8 steps back to back) into hipGraphs that
     // reads the position from device memory (the eager loop is host-launch-bound at ~5 us per tiny kernel).
-    static const bool no_graph = getenv("NORMA_HIP_NO_GRAPH") != nullptr;
+    static const bool no_graph_env = getenv("NORMA_HIP_NO_GRAPH") != nullptr;
+    const bool no_graph = no_graph_env || inv_t > 0.f;
     const int key[5] = {B, ctx->S, max_new_tokens, P, 1};
     if (!no_graph && memcmp(key, ctx->graph_key, sizeof(key)) != 0) {
         if (ctx->step_graph) { hipGraphExecDestroy(ctx->step_graph); ctx->step_graph = nullptr; }
@@ -760,7 +764,8 @@ extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_resu
         if (no_graph) {
             decoder_step(ctx, pos, nullptr, false);
             logits_from_dx(ctx, B);
-            launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, nullptr, ctx->sd);
+            if (inv_t > 0.f) launch_sample_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, inv_t, seed, clip0, attempt, ctx->sd);
+            else launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, nullptr, ctx->sd);
         } else if (pos + NH_GRAPH_STEPS - 1 <= cap - 2) {
             HIPCHK(hipGraphLaunch(ctx->multi_graph, ctx->sd));
             n = NH_GRAPH_STEPS;
@@ -804,6 +809,33 @@ extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_resu
         for (int i = n; i < C; i++) out_tokens[(size_t)b * C + i] = 0;
     }
     ctx->tm.decode_steps = steps;
+    return NH_OK;
+}
+
+extern "C" int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *results, int max_new_tokens) {
+    return decode_impl(ctx, out_tokens, results, max_new_tokens, 0.f, 0, 0, 0);
+}
+
+extern "C" int nh_decode_sampled(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *results, int max_new_tokens,
+                                 float temperature, uint64_t seed, uint32_t clip0, uint32_t attempt) {
+    if (ctx && !(temperature > 0.f)) return ctx->fail(NH_ERR_INVALID, "nh_decode_sampled: temperature must be > 0 (use nh_decode_greedy for t = 0)");
+    return decode_impl(ctx, out_tokens, results, max_new_tokens, 1.0f / temperature, seed, clip0, attempt);
+}
+
+extern "C" int nh_sample_rules(nh_ctx *ctx, const float *probs, const int32_t *tokens, int n_tokens, int last_timestamp,
+                               float temperature, uint64_t seed, uint32_t clip, uint32_t attempt, int32_t *token_out) {
+    if (!ctx || !probs || !tokens || !token_out || n_tokens < 1 || !(temperature > 0.f))
+        return ctx ? ctx->fail(NH_ERR_INVALID, "nh_sample_rules: bad arguments") : NH_ERR_INVALID;
+    if (!ctx->have_tokens) return ctx->fail(NH_ERR_STATE, "nh_sample_rules: call nh_set_tokens first");
+    hipSetDevice(ctx->dev);
+    const int V = ctx->c.vocab_size;
+    HIPCHK(hipMemcpyAsync(ctx->logits, probs, sizeof(float) * V, hipMemcpyHostToDevice, ctx->sd));
+    HIPCHK(hipMemcpyAsync(ctx->ds.tokens, tokens, sizeof(int32_t) * n_tokens, hipMemcpyHostToDevice, ctx->sd));
+    launch_sample_rules(ctx->logits, ctx->ds.n_active, ctx->ds.tokens, n_tokens, last_timestamp, ctx->suppress, ctx->tk, V,
+                        1.0f / temperature, seed, clip, attempt, ctx->sd);
+    HIPCHK(hipMemcpyAsync(token_out, ctx->ds.n_active, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipStreamSynchronize(ctx->sd));
+    HIPCHK(hipGetLastError());
     return NH_OK;
 }
 

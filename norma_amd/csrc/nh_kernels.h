@@ -186,6 +186,14 @@ struct RuleTokens { int sot, eot, lang, task, no_speech, no_timestamps, zero_sec
 void launch_logit_step(const float *logits, int V, DecodeState s, RuleTokens tk, int B, int ctx, int cap,
                        int max_new, int prompt_len, int mode, float *partials, unsigned *tickets, int32_t *pos_ptr,
                        hipStream_t st);
+// t > 0: one SAMPLED token per sequence (model.rs:340-348) under the seeded contract of include/norma_hip.h;
+// sequence b draws with clip id clip0 + b, step = its current token count
+void launch_sample_step(const float *logits, int V, DecodeState s, RuleTokens tk, int B, int ctx, int cap, int max_new,
+                        int prompt_len, float inv_t, unsigned long long seed, unsigned clip0, unsigned attempt, hipStream_t st);
+// parity view: rules + one draw on an already soft-maxed probability vector (token -1: everything masked)
+void launch_sample_rules(const float *probs_in, int32_t *token_out, const int32_t *tokens, int n_tokens, int last_ts,
+                         const uint8_t *suppress, RuleTokens tk, int V, float inv_t, unsigned long long seed, unsigned clip,
+                         unsigned attempt, hipStream_t st);
 // detect_language: logits [B][ldl] at prompt position 0 -> per-sequence language token (first maximum), optional probs [B][n]
 void launch_lang_detect(const float *logits, int V, const int32_t *lang_tokens, int n, float *probs_out, int32_t *lang_out,
                         int B, hipStream_t st);

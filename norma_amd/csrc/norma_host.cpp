@@ -89,6 +89,10 @@ int nm_model_transcribe(nm_model *m, const float *data, size_t n, int final_chun
     return 0;
 }
 
+void nm_model_set_temperature_fallback(nm_model *m, int enable, uint64_t seed) {
+    if (m && m->m) m->m->set_temperature_fallback(enable != 0, seed);
+}
+
 void nm_model_last_result(const nm_model *m, double *avg_logprob, double *no_speech_prob, int *needed_fallback,
                           int *n_tokens) {
     const DecodingResult &r = m->m->last_result();

@@ -81,6 +81,8 @@ namespace whisper {
 constexpr uint32_t SAMPLE_RATE = 16000;       // Model::SAMPLE_RATE (model.rs:52)
 constexpr size_t N_SAMPLES = NH_N_SAMPLES;    // candle m::N_SAMPLES
 constexpr double NO_SPEECH_THRESHOLD = 0.6, LOGPROB_THRESHOLD = -1.0;
+constexpr int N_TEMPERATURES = 6;
+constexpr float TEMPERATURES[N_TEMPERATURES] = {0.0f, 0.2f, 0.4f, 0.6f, 0.8f, 1.0f};  // candle m::TEMPERATURES (model.rs:175)
 
 // whisper/mod.rs:64-84 (variants that can occur on this path) + the run-time error of model.rs:44-46
 struct Error {
@@ -187,8 +189,12 @@ class Model {
         return Error{};
     }
 
-    // decode_with_fallback (model.rs:164-191) restricted to the deterministic t = 0.0 pass: the reference's
-    // fallback temperatures sample with an entropy-seeded RNG (monolingual.rs:439) and cannot be reproduced.
+    // decode_with_fallback (model.rs:164-191).  The t = 0 pass is deterministic.  The sampled attempts (t = 0.2 .. 1.0)
+    // draw from an entropy-seeded RNG in the reference (monolingual.rs:433-439) and cannot be reproduced draw for draw;
+    // here they follow the seeded sampling contract of include/norma_hip.h (same distribution).  They are OFF until
+    // set_temperature_fallback(true, seed) is called: then this is the reference's loop; while off, the t = 0 result is
+    // returned even when the reference would have gone on, and last_needed_fallback() says so.
+    void set_temperature_fallback(bool enable, uint64_t seed) { fallback_ = enable; seed_ = seed; slices_ = 0; }
     Error decode_with_fallback(const float *pcm, size_t n, DecodingResult &dr, bool &have) {
         int32_t ns = (int32_t)n;
         if (nh_logmel(ctx_, pcm, &ns, (int64_t)n, 1)) return backend_error();   // audio::pcm_to_mel + narrow, :74-88
@@ -199,17 +205,22 @@ class Model {
             } else if (nh_set_languages(ctx_, &lang_token_)) return backend_error();
         }
         std::vector<int32_t> toks(cfg_.max_target_positions);
-        nh_decode_result r{};
-        if (nh_decode_greedy(ctx_, toks.data(), &r, 0)) return backend_error(); // decode(audio_features, 0.0), :176
-        dr.tokens.assign(toks.begin(), toks.begin() + r.n_tokens);
-        dr.avg_logprob = r.avg_logprob; dr.no_speech_prob = r.no_speech_prob;
-        dr.compression_ratio = 0.0 / 0.0;                                        // f64::NAN, :387
+        have = false;
+        const uint32_t clip = slices_++;
+        for (int a = 0; a < N_TEMPERATURES && !have; a++) {                      // for &t in m::TEMPERATURES, :175
+            nh_decode_result r{};
+            if (a == 0) { if (nh_decode_greedy(ctx_, toks.data(), &r, 0)) return backend_error(); }   // decode(.., 0.0), :176
+            else if (nh_decode_sampled(ctx_, toks.data(), &r, 0, TEMPERATURES[a], seed_, clip, (uint32_t)a)) return backend_error();
+            dr.tokens.assign(toks.begin(), toks.begin() + r.n_tokens);
+            dr.avg_logprob = r.avg_logprob; dr.no_speech_prob = r.no_speech_prob;
+            dr.compression_ratio = 0.0 / 0.0;                                    // f64::NAN, :387
+            // :177-187 -- accept unless avg_logprob < -1 (compression_ratio is NaN, so that test is always false)
+            const bool needs_fallback = dr.avg_logprob < LOGPROB_THRESHOLD;
+            if (a == 0) needs_fallback_ = needs_fallback && !(dr.no_speech_prob > NO_SPEECH_THRESHOLD);
+            if (!needs_fallback || dr.no_speech_prob > NO_SPEECH_THRESHOLD || !fallback_) have = true;
+        }
         last_ = dr;
-        // :177-187 -- accept unless avg_logprob < -1 (compression_ratio is NaN, so that test is always false);
-        // a result that would need the sampled fallback is still returned (have = true) and flagged.
-        needs_fallback_ = dr.avg_logprob < LOGPROB_THRESHOLD && !(dr.no_speech_prob > NO_SPEECH_THRESHOLD);
-        have = true;
-        return Error{};
+        return Error{};                                                          // have == false: Ok(None), :189-190
     }
     const DecodingResult &last_result() const { return last_; }
     bool has_detokenizer() const { return (bool)detok_; }
@@ -225,6 +236,9 @@ class Model {
     std::function<std::string(const uint32_t *, size_t)> detok_;
     DecodingResult last_;
     bool needs_fallback_ = false;
+    bool fallback_ = false;
+    uint64_t seed_ = 0;
+    uint32_t slices_ = 0;
     bool detect_ = false;
     std::vector<int32_t> lang_tokens_;
     int32_t lang_token_ = -1;

@@ -86,6 +86,8 @@ def load_library() -> C.CDLL:
     L.nh_logmel_device.argtypes = [vp, vp, ip, C.c_int64, C.c_int]
     L.nh_encode.argtypes = [vp]
     L.nh_decode_greedy.argtypes = [vp, ip, C.POINTER(NhDecodeResult), C.c_int]
+    L.nh_decode_sampled.argtypes = [vp, ip, C.POINTER(NhDecodeResult), C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32]
+    L.nh_sample_rules.argtypes = [vp, fp, ip, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, ip]
     L.nh_transcribe_batch.argtypes = [vp, vp, ip, C.c_int64, C.c_int, ip, C.POINTER(NhDecodeResult), C.c_int]
     L.nh_detect_language.argtypes = [vp, ip, C.c_int, ip, fp]
     L.nh_set_languages.argtypes = [vp, ip]
@@ -229,6 +231,16 @@ class HipWhisper:
         self._chk(self.L.nh_decode_greedy(self._h, _ip(toks), res, max_new_tokens))
         return self._results(toks, res)
 
+    def decode_sampled(self, temperature: float, seed: int, clip0: int = 0, attempt: int = 1,
+                       max_new_tokens: int = 0) -> List[dict]:
+        """Model::decode at t > 0 (model.rs:340-348) under the seeded sampling contract of include/norma_hip.h."""
+        B = self.batch
+        toks = np.zeros((B, self.cfg.max_target_positions), dtype=np.int32)
+        res = (NhDecodeResult * B)()
+        self._chk(self.L.nh_decode_sampled(self._h, _ip(toks), res, max_new_tokens, float(temperature), int(seed),
+                                           int(clip0), int(attempt)))
+        return self._results(toks, res)
+
     def transcribe_batch_device(self, pcm_dev_ptr: int, n_samples: Sequence[int], stride: int,
                                 max_new_tokens: int = 0) -> List[dict]:
         """pcm already resident in HBM (device pointer, f32 [batch][stride])."""
@@ -284,6 +296,16 @@ class HipWhisper:
         am = C.c_int32(0)
         self._chk(self.L.nh_apply_rules(self._h, _fp(p), _ip(t), len(t), last_timestamp, _fp(out), C.byref(am)))
         return out, int(am.value)
+
+    def sample_rules(self, probs: np.ndarray, tokens: Sequence[int], last_timestamp: int, temperature: float, seed: int,
+                     clip: int = 0, attempt: int = 1) -> int:
+        """The sampler alone: rules + one seeded draw on a soft-maxed probability vector (-1: everything masked)."""
+        p = np.ascontiguousarray(probs, dtype=np.float32)
+        t = np.ascontiguousarray(tokens, dtype=np.int32)
+        tok = C.c_int32(0)
+        self._chk(self.L.nh_sample_rules(self._h, _fp(p), _ip(t), len(t), last_timestamp, float(temperature), int(seed),
+                                         int(clip), int(attempt), C.byref(tok)))
+        return int(tok.value)
 
     # -- instrumentation ---------------------------------------------------------------------------
     def set_profile_gemm(self, enable: bool):

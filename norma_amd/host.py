@@ -89,6 +89,7 @@ def _lib():
         L.nm_model_last_text.argtypes = [vp, C.c_char_p, C.c_int]
         L.nm_model_enable_language_detection.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
         L.nm_model_language_token.argtypes = [vp]
+        L.nm_model_set_temperature_fallback.argtypes = [vp, C.c_int, C.c_uint64]
         L.nm_model_free.argtypes = [vp]
         L.nm_model_transcribe.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_int32), C.c_int,
                                           C.POINTER(C.c_int), C.POINTER(C.c_size_t), C.c_char_p, C.c_int]
@@ -144,6 +145,10 @@ class Model:
         """multilingual LanguageState::Detect: tokens of `Language::iter()` (languages.rs:7-107) in order."""
         a = np.ascontiguousarray(lang_tokens, dtype=np.int32)
         _lib().nm_model_enable_language_detection(self._h, a.ctypes.data_as(C.POINTER(C.c_int32)), len(a))
+
+    def set_temperature_fallback(self, enable: bool, seed: int = 0):
+        """decode_with_fallback's sampled attempts (model.rs:175-188) on/off; draws follow the seeded sampling contract."""
+        _lib().nm_model_set_temperature_fallback(self._h, int(enable), int(seed))
 
     @property
     def language_token(self) -> int:

@@ -84,6 +84,14 @@ def lib():
         L.wo_set_language.argtypes = [C.c_void_p, C.c_int]
         L.wo_num_threads.restype = C.c_int
         L.wo_set_num_threads.argtypes = [C.c_int]
+        up = C.POINTER(C.c_uint32)
+        L.wo_philox.argtypes = [up, up, up]
+        L.wo_sexp.argtypes = [C.c_float]; L.wo_sexp.restype = C.c_float
+        L.wo_sample_token.argtypes = [fp, C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32]
+        L.wo_sample_token.restype = C.c_int
+        L.wo_decode_t.argtypes = [C.c_void_p, fp, C.c_int, C.c_int, C.c_int, ip, dp, dp, fp, C.c_double, C.c_uint64, C.c_int, C.c_int]
+        L.wo_decode_t.restype = C.c_int
+        L.wo_set_sampling.argtypes = [C.c_void_p, C.c_int, C.c_uint64]
         # never oversubscribe: GPU boxes expose every host core but grant a 16-core share
         L.wo_set_num_threads(default_threads())
         _lib = L
@@ -198,15 +206,21 @@ class OracleModel:
     def set_language(self, lang_token: int):
         lib().wo_set_language(self._h, int(lang_token))
 
-    def decode(self, xa: np.ndarray, use_kv_cache: bool = True, max_new_tokens: int = 0, want_steps=False):
+    def set_sampling(self, enable_fallback: bool, seed: int = 0):
+        """decode_with_fallback's sampled attempts (model.rs:175-188) on/off inside transcribe, and their seed."""
+        lib().wo_set_sampling(self._h, int(enable_fallback), int(seed))
+
+    def decode(self, xa: np.ndarray, use_kv_cache: bool = True, max_new_tokens: int = 0, want_steps=False,
+               temperature: float = 0.0, seed: int = 0, clip: int = 0, attempt: int = 0):
+        """Model::decode (model.rs:279-389); temperature > 0 samples under the seeded contract (whisper_oracle.c)."""
         xa = np.ascontiguousarray(xa, dtype=np.float32)
         toks = np.zeros(self.cfg.max_target_positions + 2, dtype=np.int32)
         alp = C.c_double(0)
         nsp = C.c_double(0)
         steps = np.zeros((self.cfg.max_target_positions, 4), dtype=np.float32) if want_steps else None
-        n = lib().wo_decode(self._h, _f(xa), xa.shape[0], USE_KV_CACHE if use_kv_cache else 0,
-                            max_new_tokens, _i(toks), C.byref(alp), C.byref(nsp),
-                            _f(steps) if want_steps else None)
+        n = lib().wo_decode_t(self._h, _f(xa), xa.shape[0], USE_KV_CACHE if use_kv_cache else 0,
+                              max_new_tokens, _i(toks), C.byref(alp), C.byref(nsp),
+                              _f(steps) if want_steps else None, float(temperature), int(seed), int(clip), int(attempt))
         res = dict(tokens=toks[:n].tolist(), avg_logprob=alp.value, no_speech_prob=nsp.value)
         if want_steps:
             res["steps"] = steps
@@ -240,3 +254,23 @@ class OracleModel:
                 cur.append(t)
         return segs, work[:blen.value].copy(), dict(n_slices=ns.value, avg_logprob=alp.value,
                                                     no_speech_prob=nsp.value)
+
+
+def philox(ctr, key):
+    """philox4x32-10 (the sampling contract's generator): 4 + 2 uint32 in, 4 uint32 out."""
+    c = (C.c_uint32 * 4)(*[int(v) & 0xFFFFFFFF for v in ctr])
+    k = (C.c_uint32 * 2)(*[int(v) & 0xFFFFFFFF for v in key])
+    o = (C.c_uint32 * 4)()
+    lib().wo_philox(c, k, o)
+    return [int(v) for v in o]
+
+
+def sexp(y: float) -> float:
+    return float(lib().wo_sexp(float(y)))
+
+
+def sample_token(q: np.ndarray, temperature: float, seed: int, clip: int, step: int, attempt: int) -> int:
+    """Draw from softmax(q / t) of the rule-masked probabilities q under the seeded contract; -1: everything masked."""
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    inv_t = np.float32(1.0) / np.float32(temperature)
+    return int(lib().wo_sample_token(_f(q), len(q), float(inv_t), int(seed), int(clip), int(step), int(attempt)))

@@ -99,6 +99,9 @@ typedef struct wo_model {
     wo_tokens tk;
     float *suppress_tokens, *supress_non_timestamps, *supress_timestamps, *first_token_supress;
     int self_cache_len;
+    /* decode_with_fallback's sampled attempts (model.rs:175-188): off = return the t = 0 result (needed_fallback is
+     * reported); on = temperatures 0.2 .. 1.0 under the seeded sampling contract; `slices` numbers the decoded slices */
+    int fallback; uint64_t sample_seed; uint32_t slices;
 } wo_model;
 
 /* ------------------------------------------------------------------------------------------ */
@@ -790,13 +793,97 @@ int wo_detect_language(wo_model *m, const float *xa, int S, const int *lang_toke
 void wo_set_language(wo_model *m, int lang_token) { m->tk.lang = lang_token; } /* LanguageState::set_language_token */
 
 /* ------------------------------------------------------------------------------------------ */
+/* Sampled decoding at t > 0 (model.rs:340-348).  The reference draws from rand's WeightedIndex */
+/* with an entropy-seeded StdRng (model.rs:30, monolingual.rs:433), so only the DISTRIBUTION   */
+/* can be matched; what is restated here is the distribution, under this build's seeded        */
+/* contract (include/norma_hip.h, "sampling contract"), which the HIP path follows bit for bit: */
+/*   weights  w_i = sexp((q_i - max q) * inv_t), q = the rule-masked probabilities (:333-338),  */
+/*            i.e. softmax(q / t) of :341 up to its normalisation, which WeightedIndex ignores; */
+/*   uniform  u = (philox4x32-10(key = seed, ctr = {step, clip, attempt, "norm"})[0] >> 8) 2^-24 */
+/*   choice   first j whose cumulative weight exceeds u * total  (WeightedIndex::sample's       */
+/*            partition_point), cumulated in f64 over chunks of ceil(V / 1024) tokens.           */
+/* ------------------------------------------------------------------------------------------ */
+static void philox4x32_10(const uint32_t ctr_in[4], const uint32_t key_in[2], uint32_t out[4]) {
+    uint32_t c0 = ctr_in[0], c1 = ctr_in[1], c2 = ctr_in[2], c3 = ctr_in[3], k0 = key_in[0], k1 = key_in[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+void wo_philox(const uint32_t *ctr, const uint32_t *key, uint32_t *out) { philox4x32_10(ctr, key, out); }
+
+/* exp(y) for y <= 0 from IEEE f32 operations only (Cephes expf polynomial), so that the C and the HIP side round alike */
+static float sexp(float y) {
+    if (!(y >= -87.0f)) return 0.0f; /* also -inf and NaN: a masked token has weight 0 */
+    float kf = floorf(fmaf(y, 1.44269504088896341f, 0.5f));
+    float r = fmaf(kf, -0.693359375f, y);
+    r = fmaf(kf, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float z = r * r;
+    float res = fmaf(p, z, r) + 1.0f;
+    union { uint32_t u; float f; } sc;
+    sc.u = (uint32_t)((int)kf + 127) << 23;
+    return res * sc.f;
+}
+float wo_sexp(float y) { return sexp(y); }
+
+/* q: rule-masked probabilities [V].  Returns the sampled token, or -1 when every entry is masked (the reference pushes
+ * eot and stops, model.rs:343-346). */
+int wo_sample_token(const float *q, int V, float inv_t, uint64_t seed, uint32_t clip, uint32_t step, uint32_t attempt) {
+    float qmax = -INFINITY;
+    for (int i = 0; i < V; i++) if (q[i] > qmax) qmax = q[i];
+    if (!(qmax > -INFINITY)) return -1;
+    const int CH = (V + 1023) / 1024;
+    double chunk[1024];
+    for (int c = 0; c < 1024; c++) {
+        double sc = 0.0;
+        for (int i = c * CH; i < (c + 1) * CH && i < V; i++) sc += (double)sexp((q[i] - qmax) * inv_t);
+        chunk[c] = sc;
+    }
+    double total = 0.0;
+    for (int c = 0; c < 1024; c++) total += chunk[c];
+    uint32_t ctr[4] = {step, clip, attempt, 0x6e6f726du}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, r[4];
+    philox4x32_10(ctr, key, r);
+    const float u = (float)(r[0] >> 8) * (1.0f / 16777216.0f);
+    const double x = (double)u * total;
+    double run = 0.0;
+    int c = 0;
+    for (; c < 1023; c++) { if (run + chunk[c] > x) break; run += chunk[c]; }
+    int last_pos = -1;
+    for (int i = c * CH; i < V; i++) { /* walks on past the chunk only if rounding left x >= the chunk's end */
+        const float w = sexp((q[i] - qmax) * inv_t);
+        if (w > 0.0f) last_pos = i;
+        run += (double)w;
+        if (run > x) return i;
+    }
+    return last_pos; /* x == total exactly: the last token with weight */
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Model::decode at t = 0 (model.rs:279-389)                                                  */
 /* ------------------------------------------------------------------------------------------ */
 /* tokens_out must hold n_text_ctx + 1 ints.  max_new_tokens <= 0: reference behaviour (cap at
  * n_text_ctx - 1 tokens).  step_probs (optional, [cap][4]): per generated token
  * {p(next), best competing masked prob, sum_ts, max_text} for margin analysis in tests. */
+int wo_decode_t(wo_model *m, const float *xa, int S, int flags, int max_new_tokens, int *tokens_out,
+                double *avg_logprob, double *no_speech_prob, float *step_probs, double temperature, uint64_t seed,
+                int clip, int attempt);
 int wo_decode(wo_model *m, const float *xa, int S, int flags, int max_new_tokens, int *tokens_out,
               double *avg_logprob, double *no_speech_prob, float *step_probs) {
+    return wo_decode_t(m, xa, S, flags, max_new_tokens, tokens_out, avg_logprob, no_speech_prob, step_probs, 0.0, 0, 0, 0);
+}
+/* temperature > 0: the token is sampled (model.rs:340-348) under the seeded contract above */
+int wo_decode_t(wo_model *m, const float *xa, int S, int flags, int max_new_tokens, int *tokens_out,
+                double *avg_logprob, double *no_speech_prob, float *step_probs, double temperature, uint64_t seed,
+                int clip, int attempt) {
     int V = m->c.n_vocab, d = m->c.d, cap = m->c.n_text_ctx - 1;
     int *tokens = tokens_out, n = 0;
     double sum_logprob = 0.0;
@@ -831,7 +918,13 @@ int wo_decode(wo_model *m, const float *xa, int S, int flags, int max_new_tokens
         softmax_row(logits, V); /* :331 -- masks are applied to probabilities from here on */
         if (have_last) wo_apply_rules(m, logits, tokens, n, last_timestamp);
         else add_mask(logits, m->first_token_supress, V); /* :336-337 */
-        int next = wo_argmax_total(logits, V);            /* :350-356 */
+        int next;
+        if (temperature > 0.0) { /* :340-348 */
+            next = wo_sample_token(logits, V, 1.0f / (float)temperature, seed, (uint32_t)clip, (uint32_t)n, (uint32_t)attempt);
+            if (next < 0) { tokens[n++] = m->tk.eot; break; } /* all NaN: push eot, stop */
+        } else {
+            next = wo_argmax_total(logits, V);            /* :350-356 */
+        }
         if (step_probs) {
             float second = -INFINITY, sum_ts = 0.f, max_text = -INFINITY;
             for (int i = 0; i < V; i++) {
@@ -907,12 +1000,24 @@ int wo_transcribe(wo_model *m, const float *filters, float *buf, long *buf_len, 
         float *xa = (float *)xcalloc((size_t)S * d, sizeof(float));
         wo_encoder_forward(m, mel, frames, n_len, xa); /* decode_with_fallback :168 */
         free(mel);
-        double alp, nsp;
-        int n = wo_decode(m, xa, S, flags, max_new_tokens, tokens, &alp, &nsp, NULL); /* t = 0.0 only (H2) */
+        double alp = 0.0, nsp = 0.0;
+        int n = 0, have = 0;
+        static const double temps[6] = {0.0, 0.2, 0.4, 0.6, 0.8, 1.0}; /* candle m::TEMPERATURES */
+        for (int a = 0; a < 6 && !have; a++) { /* decode_with_fallback, :175-188 */
+            n = wo_decode_t(m, xa, S, flags, max_new_tokens, tokens, &alp, &nsp, NULL, temps[a], m->sample_seed, (int)m->slices, a);
+            int needs_fallback = alp < -1.0; /* compression_ratio is NaN: that comparison is always false (:177) */
+            if (!needs_fallback || nsp > 0.6 || !m->fallback) have = 1;
+        }
+        m->slices++;
         free(xa);
         (*n_slices)++;
         *last_avg_logprob = alp; *last_no_speech = nsp;
         int drained = 0;
+        if (!have) { /* :89-92: no attempt was acceptable */
+            memmove(buf, buf + slice_len, sizeof(float) * (size_t)(*buf_len - slice_len));
+            *buf_len -= slice_len;
+            continue;
+        }
         if (nsp > 0.6 && alp < -1.0) { /* :95-98 */
             memmove(buf, buf + slice_len, sizeof(float) * (size_t)(*buf_len - slice_len));
             *buf_len -= slice_len;
@@ -958,6 +1063,8 @@ int wo_transcribe(wo_model *m, const float *filters, float *buf, long *buf_len, 
     free(tokens);
     return n_out;
 }
+
+void wo_set_sampling(wo_model *m, int enable_fallback, uint64_t seed) { m->fallback = enable_fallback; m->sample_seed = seed; m->slices = 0; }
 
 void wo_set_num_threads(int n) {
 #ifdef _OPENMP

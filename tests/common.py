@@ -23,6 +23,11 @@ def tokens_for(name):
     return vocab.VOCABS[config.preset_vocab(name)]
 
 
+def oracle_module():
+    from oracle import oracle as O
+    return O
+
+
 def build_oracle(cfg, tk, seed=0, overrides=None, lang=None):
     from oracle import oracle as O
     om = O.OracleModel(cfg, tk, tk.en if lang is None else lang, tk.transcribe)
