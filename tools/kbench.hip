@@ -55,7 +55,20 @@ int main(int argc, char **argv) {
         p.out[0] = o0; p.out[1] = sk; p.out[2] = sv; p.ldo = ldo; p.d = d; p.t0 = 5; p.Tn = 1; p.ctx = C;
         launch_skinny(p, slabs, tick, st);
     };
+    auto ln_call = [&](half_t *W, int N, int K, int epi, void *o0, long ldo) {  // LayerNorm fused into the GEMV
+        SkinnyParams p{}; p.x = nullptr; p.ldx = K; p.W = W; p.bias = bias; p.R = B; p.N = N; p.K = K; p.epi = epi;
+        p.out[0] = o0; p.out[1] = sk; p.out[2] = sv; p.ldo = ldo; p.d = d; p.t0 = 5; p.Tn = 1; p.ctx = C;
+        p.ln_x = x; p.ln_w = lnw; p.ln_b = lnb;
+        launch_skinny(p, slabs, tick, st);
+    };
     const int R = 100;
+    if (skinny_ln_supported(B, 3 * d, d)) {
+        bench("LN+qkv   N=3840 K=1280 (fused)", R, [&] { ln_call(W(3ul * d * d), 3 * d, d, SK_QKV, q, d); }, 3.0 * d * d * 2);
+        bench("LN+cq    N=1280 K=1280 (fused)", R, [&] { ln_call(W(1ul * d * d), d, d, SK_F16, q, d); }, 1.0 * d * d * 2);
+        bench("LN+fc1   N=5120 K=1280 (fused)", R, [&] { ln_call(W(4ul * d * d), 4 * d, d, SK_GELU_F16, hid, 4 * d); }, 4.0 * d * d * 2);
+        bench("LN+logits N=51866 K=1280 (fused)", 9, [&] { SkinnyParams p{}; p.ldx = d; p.W = W((size_t)V * d); p.R = B; p.N = V; p.K = d; p.epi = SK_F32; p.out[0] = logits; p.ldo = VP; p.ln_x = x; p.ln_w = lnw; p.ln_b = lnb; launch_skinny(p, slabs, tick, st); }, (double)V * d * 2);
+    }
+    bench("layernorm (sliced) B rows", R, [&] { launch_layernorm_sliced(x, lnw, lnb, xn, nullptr, B, d, st); });
     bench("layernorm B rows", R, [&] { launch_layernorm(x, lnw, lnb, xn, nullptr, B, d, st); });
     bench("embed", R, [&] { launch_embed(ds.tokens, 4096, w_e, w_e, x, B, 1, 5, nullptr, d, st); });
     bench("skinny qkv   N=3840 K=1280 (SK_QKV)", R, [&] { sk_call(xn, d, W(3ul * d * d), 3 * d, d, SK_QKV, q, d); }, 3.0 * d * d * 2);
