@@ -70,13 +70,13 @@ __device__ __forceinline__ void skinny_store(const SkinnyParams &p, f32x4 v, int
 // U k-steps of one wave: all loads issued back to back (never guarded: a guarded load makes hipcc drain
 // vmcnt(0) per element), then the MFMAs.  The callers cover `steps` with groups of 10, 5, 2 and 1.
 template <int U, int NT, int NCB>
-__device__ __forceinline__ void skinny_group(const half_t *const (&wp)[NT], const half_t *const (&xp)[NCB], int s0,
+__device__ __forceinline__ void skinny_group(const half_t *const (&wp)[NT], int wstep, const half_t *const (&xp)[NCB], int s0,
                                              f32x4 (&acc)[NT][NCB]) {
     half8 a[NT][U], b[NCB][U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
 #pragma unroll
-        for (int t = 0; t < NT; t++) a[t][u] = *reinterpret_cast<const half8 *>(wp[t] + 32 * (s0 + u));
+        for (int t = 0; t < NT; t++) a[t][u] = *reinterpret_cast<const half8 *>(wp[t] + (long)wstep * (s0 + u));
 #pragma unroll
         for (int cb = 0; cb < NCB; cb++) b[cb][u] = *reinterpret_cast<const half8 *>(xp[cb] + 32 * (s0 + u));
     }
@@ -116,11 +116,14 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
         }
     }
     const int kslice = p.K / (KSPLIT * KS), kbeg = KSPLIT == 1 ? 0 : (ks * KSPLIT + w) * kslice;
+    // weights: row-major [N][K] (a wave instruction = 16 rows x 64 B) or the tile-major repack (1 KiB contiguous)
     const half_t *wp[NT];
+    const int wstep = p.Wt ? 512 : 32;
 #pragma unroll
     for (int t = 0; t < NT; t++) {
         int wrow = n0 + 16 * t + fr; if (wrow >= p.N) wrow = p.N - 1;
-        wp[t] = p.W + (long)wrow * p.K + kbeg + 8 * fq;
+        wp[t] = p.Wt ? p.Wt + ((long)((n0 >> 4) + t) * (p.K >> 5) + (kbeg >> 5)) * 512 + lane * 8
+                     : p.W + (long)wrow * p.K + kbeg + 8 * fq;
     }
     const half_t *xp[NCB];
 #pragma unroll
@@ -136,10 +139,10 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
     const int steps = kslice >> 5;
     {
         int s0 = 0;
-        for (; s0 + 10 <= steps; s0 += 10) skinny_group<10, NT, NCB>(wp, xp, s0, acc);
-        if (s0 + 5 <= steps) { skinny_group<5, NT, NCB>(wp, xp, s0, acc); s0 += 5; }
-        for (; s0 + 2 <= steps; s0 += 2) skinny_group<2, NT, NCB>(wp, xp, s0, acc);
-        if (s0 < steps) skinny_group<1, NT, NCB>(wp, xp, s0, acc);
+        for (; s0 + 10 <= steps; s0 += 10) skinny_group<10, NT, NCB>(wp, wstep, xp, s0, acc);
+        if (s0 + 5 <= steps) { skinny_group<5, NT, NCB>(wp, wstep, xp, s0, acc); s0 += 5; }
+        for (; s0 + 2 <= steps; s0 += 2) skinny_group<2, NT, NCB>(wp, wstep, xp, s0, acc);
+        if (s0 < steps) skinny_group<1, NT, NCB>(wp, wstep, xp, s0, acc);
     }
     if (KSPLIT == 1) {
         // D[n = 4 fq + i][r = 16 cb + fr]: each lane already holds 4 consecutive features of one row
@@ -215,10 +218,11 @@ __global__ __launch_bounds__(256) void skinny_ln_kernel(SkinnyParams p) {
     const int kbeg = w * 32 * STEPS;
     // weights first: the only HBM stream of the kernel
     int wrow = n0 + fr; if (wrow >= p.N) wrow = p.N - 1;
-    const half_t *wp = p.W + (long)wrow * K + kbeg + 8 * fq;
+    const half_t *wp = p.Wt ? p.Wt + ((long)blockIdx.x * (K >> 5) + (kbeg >> 5)) * 512 + lane * 8 : p.W + (long)wrow * K + kbeg + 8 * fq;
+    const int wstep = p.Wt ? 512 : 32;
     half8 a[STEPS];
 #pragma unroll
-    for (int s = 0; s < STEPS; s++) a[s] = *reinterpret_cast<const half8 *>(wp + 32 * s);
+    for (int s = 0; s < STEPS; s++) a[s] = *reinterpret_cast<const half8 *>(wp + wstep * s);
     // epilogue operands of the element this thread will own (see skinny_gemm_kernel)
     f32x4 pre[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const bool can_pre = (p.N & 3) == 0;
@@ -375,6 +379,37 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(SkinnyParams p) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int rows = 16 * NCB, steps = p.K >> 5;
+    // Work split: every wave of the grid owns a contiguous range of weight rows, 4-row units dealt out evenly (24 or 28 rows
+    // at V = 51866 over 2048 waves; whole 16-row tiles per wave left 42 % of the waves with half the work of the others).
+    // A tile that sticks out of the range clamps its rows to the last one (cache hits, not HBM) and masks the stores.
+    // With the tile-major repack (p.Wt: 1 KiB contiguous per wave instruction, 5.1 vs 3.7 TB/s for this stream) the unit is
+    // a whole 16-row tile, dealt out round-robin.
+    const int gw = blockIdx.x * 8 + w, nwav = gridDim.x * 8;
+    const bool tiled = p.Wt != nullptr;
+    const int units = (p.N + 3) >> 2, upw = units / nwav, uex = units % nwav;
+    const int ntiles = (p.N + 15) >> 4;
+    const int lo = tiled ? 16 * gw : 4 * (gw * upw + (gw < uex ? gw : uex));
+    int hi = tiled ? p.N : lo + 4 * (upw + (gw < uex ? 1 : 0)); if (hi > p.N) hi = p.N;
+    const int tstride = tiled ? nwav : 1;  // tile t of this wave starts at row lo + 16 t tstride
+    const int my_tiles = tiled ? (gw < ntiles ? (ntiles - gw + nwav - 1) / nwav : 0) : ((hi - lo + 15) >> 4);
+    const int ngrp = (steps + SK_U - 1) / SK_U;
+    const int G = my_tiles * ngrp;  // (tile, k-group) pairs of this wave, k-groups innermost
+    // one k-group of weight-row segments: unconditional clamped loads, all in flight together
+    auto issue = [&](int g, half8 (&a)[SK_U]) {
+        const int tile = g / ngrp, s0 = (g - tile * ngrp) * SK_U;
+        const int row0 = lo + 16 * tile * tstride;
+        int wrow = row0 + fr; if (wrow > hi - 1) wrow = hi - 1;
+        const half_t *wp = tiled ? p.Wt + (long)(row0 >> 4) * steps * 512 + lane * 8 : p.W + (long)wrow * p.K + 8 * fq;
+        const int wstep = tiled ? 512 : 32;
+#pragma unroll
+        for (int u = 0; u < SK_U; u++) {
+            const int sc = s0 + u < steps ? s0 + u : steps - 1;
+            a[u] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(wp + (long)wstep * sc));  // 133 MB read once per token
+        }
+    };
+    // the first group is requested BEFORE the activations are staged (and normalised): the weights do not depend on them
+    half8 a0[SK_U], a1[SK_U];
+    if (G > 0) issue(0, a0);
     if (p.ln_x) {
         // fused final LayerNorm (sliced tree, 16 lanes per row, 32 rows per pass), written as the swizzled fp16 image
         for (int r = tid >> 4; r < rows; r += 32) {
@@ -403,42 +438,66 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(SkinnyParams p) {
         }
     }
     __syncthreads();
-    const int tiles = (p.N + 15) >> 4;
-    const int nwaves = gridDim.x * 8;
     int boff[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) boff[cb] = (16 * cb + fr) * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
-    for (int tile = blockIdx.x * 8 + w; tile < tiles; tile += nwaves) {
-        const int n0 = tile * 16;
-        int wrow = n0 + fr; if (wrow >= p.N) wrow = p.N - 1;
-        const half_t *wp = p.W + (long)wrow * p.K + 8 * fq;
-        f32x4 acc[NCB];
+    f32x4 acc[NCB];
+    auto compute = [&](int g, const half8 (&a)[SK_U]) {
+        const int tile = g / ngrp, gi = g - tile * ngrp, s0 = gi * SK_U;
+        if (gi == 0) {
 #pragma unroll
-        for (int cb = 0; cb < NCB; cb++) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int s0 = 0; s0 < steps; s0 += SK_U) {
-            half8 a[SK_U];
+            for (int cb = 0; cb < NCB; cb++) acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
-            for (int u = 0; u < SK_U; u++) {
-                const int sc = s0 + u < steps ? s0 + u : steps - 1;  // unconditional, clamped
-                a[u] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(wp + 32 * sc));  // 133 MB read once per token
-            }
+        for (int u = 0; u < SK_U; u++) {
+            if (s0 + u < steps) {
 #pragma unroll
-            for (int u = 0; u < SK_U; u++) {
-                if (s0 + u < steps) {
-#pragma unroll
-                    for (int cb = 0; cb < NCB; cb++) {
-                        half8 b = *reinterpret_cast<const half8 *>(xs + (long)(s0 + u) * rows * 64 + boff[cb]);
-                        acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b, acc[cb], 0, 0, 0);
-                    }
+                for (int cb = 0; cb < NCB; cb++) {
+                    half8 b = *reinterpret_cast<const half8 *>(xs + (long)(s0 + u) * rows * 64 + boff[cb]);
+                    acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b, acc[cb], 0, 0, 0);
                 }
             }
         }
+        if (gi == ngrp - 1) {
+            const int n = lo + 16 * tile * tstride + 4 * fq;  // lo and hi are multiples of 4 (hi may be N itself)
+            if (n < hi) {
 #pragma unroll
-        for (int cb = 0; cb < NCB; cb++) {
-            int r = 16 * cb + fr;
-            if (r < p.R) skinny_store(p, acc[cb], r, n0 + 4 * fq);
+                for (int cb = 0; cb < NCB; cb++) {
+                    int r = 16 * cb + fr;
+                    if (r < p.R) skinny_store(p, acc[cb], r, n);
+                }
+            }
         }
+    };
+    // two register sets: the next group is in flight while the current one is multiplied
+    for (int g = 0; g < G; g += 2) {
+        if (g + 1 < G) issue(g + 1, a1);
+        compute(g, a0);
+        if (g + 2 < G) issue(g + 2, a0);
+        if (g + 1 < G) compute(g + 1, a1);
     }
+}
+
+// tile-major repack of a row-major [N][K] fp16 weight: out[(tile * K/32 + s) * 512 + lane * 8 + j] =
+// W[16 tile + (lane & 15)][32 s + 8 (lane >> 4) + j], rows >= N zero: the MFMA A fragment of (tile, k-step s) is 1 KiB contiguous
+__global__ __launch_bounds__(256) void repack_tiles_kernel(const half_t *__restrict__ W, half_t *__restrict__ out, int N, int K) {
+    const long chunk = blockIdx.x * 256L + threadIdx.x;  // one 16-byte chunk per thread
+    const int steps = K >> 5;
+    const long total = (long)((N + 15) >> 4) * steps * 64;
+    if (chunk >= total) return;
+    const int lane = (int)(chunk & 63);
+    const long ts = chunk >> 6;
+    const int s = (int)(ts % steps);
+    const long tile = ts / steps;
+    const long row = tile * 16 + (lane & 15);
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (row < N) v = *reinterpret_cast<const u32x4 *>(W + row * K + 32 * s + 8 * (lane >> 4));
+    *reinterpret_cast<u32x4 *>(out + chunk * 8) = v;
+}
+
+void launch_repack_tiles(const half_t *W, half_t *out, int N, int K, hipStream_t st) {
+    const long total = (long)((N + 15) >> 4) * (K >> 5) * 64;
+    hipLaunchKernelGGL(repack_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, out, N, K);
 }
 
 static bool ln_steps_ok(int K) {

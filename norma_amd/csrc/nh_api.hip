@@ -26,7 +26,7 @@
 
 static std::string g_create_error;
 
-struct LinW { half_t *w = nullptr; float *b = nullptr; };
+struct LinW { half_t *w = nullptr; float *b = nullptr; half_t *wt = nullptr; /* tile-major repack (decoder GEMVs) */ };
 struct LnW { float *w = nullptr, *b = nullptr; };
 struct EncLayer { LnW ln1, ln2; LinW qkv, o, fc1, fc2; };
 struct DecLayer { LnW ln1, ln2, ln3; LinW qkv, o, cq, ckv, co, fc1, fc2; half_t *ck = nullptr, *cv = nullptr, *sk = nullptr, *sv = nullptr; };
@@ -47,6 +47,8 @@ struct nh_ctx {
     std::vector<EncLayer> enc;
     LnW ln_post, dec_ln;
     half_t *tok_emb = nullptr, *dec_pos = nullptr;
+    half_t *tok_emb_t = nullptr;     // tile-major repack of the tied embedding (logits GEMV)
+    bool dec_tiled_valid = false;    // the repacks mirror the row-major decoder weights loaded so far
     std::vector<DecLayer> dec;
     std::set<std::string> expected, loaded;
     // mel
@@ -408,8 +410,32 @@ extern "C" int nh_load_tensor(nh_ctx *ctx, const char *name_c, int dtype, const 
             else return ctx->fail(NH_ERR_INVALID, "nh_load_tensor: unhandled tensor " + name);
         }
     }
-    if (rc == NH_OK) ctx->loaded.insert(name);
+    if (rc == NH_OK) { ctx->loaded.insert(name); ctx->dec_tiled_valid = false; }
     return rc;
+}
+
+// The decoder's GEMVs stream every weight once per token: repack them tile-major (launch_repack_tiles) so that a wave
+// instruction reads 1 KiB contiguous instead of 16 row pieces of 64 B.  Done lazily before the first decoder use and
+// again after any nh_load_tensor; the row-major originals stay (embedding lookup, cross-K/V GEMM, re-loading).
+static int ensure_decoder_repack(nh_ctx *ctx) {
+    if (ctx->dec_tiled_valid) return NH_OK;
+    const int d = ctx->c.d_model, V = ctx->c.vocab_size;
+    auto one = [&](half_t *&dst, const half_t *src, int N, int K) -> bool {
+        if (!dst) dst = dalloc<half_t>(ctx, (size_t)((N + 15) / 16) * 16 * K, false);
+        if (!dst) return false;
+        launch_repack_tiles(src, dst, N, K, ctx->sd);
+        return true;
+    };
+    bool ok = one(ctx->tok_emb_t, ctx->tok_emb, V, d);
+    for (auto &L : ctx->dec) {
+        ok = ok && one(L.qkv.wt, L.qkv.w, 3 * d, d) && one(L.o.wt, L.o.w, d, d) && one(L.cq.wt, L.cq.w, d, d) &&
+             one(L.co.wt, L.co.w, d, d) && one(L.fc1.wt, L.fc1.w, 4 * d, d) && one(L.fc2.wt, L.fc2.w, d, 4 * d);
+    }
+    if (!ok) return ctx->fail(NH_ERR_NOMEM, "hipMalloc(tile-major decoder weights)");
+    HIPCHK(hipStreamSynchronize(ctx->sd));
+    HIPCHK(hipGetLastError());
+    ctx->dec_tiled_valid = true;
+    return NH_OK;
 }
 
 extern "C" int nh_missing_tensors(const nh_ctx *ctx) {
@@ -629,7 +655,7 @@ static void skinny(nh_ctx *ctx, const half_t *x, long ldx, const LinW &W, int R,
                    const float *ln_w = nullptr, const float *ln_b = nullptr) {
     SkinnyParams p{};
     p.pos_ptr = pos_ptr; p.ln_x = ln_x; p.ln_w = ln_w; p.ln_b = ln_b;
-    p.x = x; p.ldx = ldx; p.W = W.w; p.bias = W.b; p.R = R; p.N = N; p.K = K; p.epi = epi;
+    p.x = x; p.ldx = ldx; p.W = W.w; p.Wt = W.wt; p.bias = W.b; p.R = R; p.N = N; p.K = K; p.epi = epi;
     p.out[0] = o0; p.out[1] = o1; p.out[2] = o2; p.ldo = ldo; p.d = ctx->c.d_model; p.t0 = t0; p.Tn = 1; p.ctx = ctxlen;
     launch_skinny(p, ctx->sk_slabs, ctx->sk_tickets, ctx->sd);
 }
@@ -673,7 +699,7 @@ static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr,
 
 // TextDecoder::final_linear on LN(dx) of the R rows of the last decoder_step(..., final_ln = false)
 static void logits_from_dx(nh_ctx *ctx, int R) {
-    LinW E; E.w = ctx->tok_emb; E.b = nullptr;  // tied embedding, no bias (final_linear)
+    LinW E; E.w = ctx->tok_emb; E.wt = ctx->tok_emb_t; E.b = nullptr;  // tied embedding, no bias (final_linear)
     const int d = ctx->c.d_model, V = ctx->c.vocab_size;
     if (skinny_ln_supported(R, V, d)) {
         skinny(ctx, nullptr, d, E, R, V, d, SK_F32, ctx->logits, nullptr, nullptr, ctx->VP, 0, 0, nullptr, ctx->dx, ctx->dec_ln.w, ctx->dec_ln.b);
@@ -684,7 +710,7 @@ static void logits_from_dx(nh_ctx *ctx, int R) {
 }
 
 static void logits_from_dxn(nh_ctx *ctx, int R) {
-    LinW E; E.w = ctx->tok_emb; E.b = nullptr;
+    LinW E; E.w = ctx->tok_emb; E.wt = ctx->tok_emb_t; E.b = nullptr;
     skinny(ctx, ctx->dxn, ctx->c.d_model, E, R, ctx->c.vocab_size, ctx->c.d_model, SK_F32, ctx->logits, nullptr, nullptr,
            ctx->VP, 0, 0);
 }
@@ -697,6 +723,7 @@ static int decode_impl(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *resul
     if (!ctx->have_enc) return ctx->fail(NH_ERR_STATE, "nh_decode: call nh_encode first");
     if (!ctx->have_tokens) return ctx->fail(NH_ERR_STATE, "nh_decode: call nh_set_tokens first");
     hipSetDevice(ctx->dev);
+    if (int rc = ensure_decoder_repack(ctx)) return rc;
     const int B = ctx->cur_batch, C = ctx->c.max_target_positions, cap = C - 1, V = ctx->c.vocab_size;
     // model.rs:285-289: prompt = [sot, lang?, task]
     const bool per_seq = (int)ctx->seq_lang.size() == B;
@@ -856,6 +883,7 @@ extern "C" int nh_detect_language(nh_ctx *ctx, const int32_t *lang_tokens, int n
     if (!ctx->have_enc) return ctx->fail(NH_ERR_STATE, "nh_detect_language: call nh_encode first");
     if (!ctx->have_tokens) return ctx->fail(NH_ERR_STATE, "nh_detect_language: call nh_set_tokens first");
     hipSetDevice(ctx->dev);
+    if (int rc = ensure_decoder_repack(ctx)) return rc;
     const int B = ctx->cur_batch, C = ctx->c.max_target_positions, V = ctx->c.vocab_size;
     for (int i = 0; i < n; i++) if (lang_tokens[i] < 0 || lang_tokens[i] >= V) return ctx->fail(NH_ERR_INVALID, "nh_detect_language: token id outside the vocabulary");
     std::vector<int32_t> toks((size_t)B * C, 0);
@@ -903,6 +931,7 @@ extern "C" int nh_decoder_forward(nh_ctx *ctx, const int32_t *tokens, int T, flo
     const int B = ctx->cur_batch, C = ctx->c.max_target_positions, d = ctx->c.d_model, V = ctx->c.vocab_size;
     if (T < 1 || T > C) return ctx->fail(NH_ERR_INVALID, "nh_decoder_forward: T out of range");
     hipSetDevice(ctx->dev);
+    if (int rc = ensure_decoder_repack(ctx)) return rc;
     HIPCHK(hipStreamWaitEvent(ctx->sd, ctx->enc_done, 0));
     std::vector<int32_t> toks((size_t)B * C, 0);
     for (int b = 0; b < B; b++)
@@ -928,6 +957,7 @@ extern "C" int nh_final_linear(nh_ctx *ctx, const float *x, int rows, float *log
     if (!ctx || !x || !logits_out) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_final_linear: bad arguments") : NH_ERR_INVALID;
     if (rows < 1) return ctx->fail(NH_ERR_INVALID, "nh_final_linear: rows must be >= 1");
     hipSetDevice(ctx->dev);
+    if (int rc = ensure_decoder_repack(ctx)) return rc;
     const int d = ctx->c.d_model, V = ctx->c.vocab_size;
     std::vector<_Float16> h((size_t)ctx->B * d);
     for (int r0 = 0; r0 < rows; r0 += ctx->B) {  // the workspace holds max_batch rows at a time

@@ -49,6 +49,7 @@ enum SkinnyEpi {
 struct SkinnyParams {
     const half_t *x; long ldx;  // [R][K] fp16
     const half_t *W; const float *bias;
+    const half_t *Wt;           // optional tile-major repack of W (launch_repack_tiles); the kernels prefer it
     int R, N, K;
     int epi;
     void *out[3]; long ldo;
@@ -128,6 +129,9 @@ bool launch_layernorm_sliced(const float *x, const float *w, const float *b, hal
 // slabs: f32 [SKINNY_MAX_TILES][8][64][16] scratch for cross-workgroup split-K (nullptr: never split across
 // workgroups); tickets: u32 [SKINNY_MAX_TILES], zero-initialised, self-resetting
 void launch_skinny(const SkinnyParams &p, float *slabs, unsigned *tickets, hipStream_t st);
+// out: ceil(N/16) * 16 * K halfs.  Tile-major: the MFMA A fragment of (16-row tile, 32-deep k-step) is 1 KiB contiguous, so a
+// GEMV streams its weights like a memcpy (the row-major form reads 16 x 64 B per wave instruction: 3.7 vs 5.1 TB/s).
+void launch_repack_tiles(const half_t *W, half_t *out, int N, int K, hipStream_t st);
 
 // ---- elementwise / normalisation -------------------------------------------------------------------
 // LayerNorm over rows of f32 x[M][d] -> fp16 y[M][d] (and optionally f32 y32[M][d])

@@ -68,6 +68,24 @@ int main(int argc, char **argv) {
         bench("LN+fc1   N=5120 K=1280 (fused)", R, [&] { ln_call(W(4ul * d * d), 4 * d, d, SK_GELU_F16, hid, 4 * d); }, 4.0 * d * d * 2);
         bench("LN+logits N=51866 K=1280 (fused)", 9, [&] { SkinnyParams p{}; p.ldx = d; p.W = W((size_t)V * d); p.R = B; p.N = V; p.K = d; p.epi = SK_F32; p.out[0] = logits; p.ldo = VP; p.ln_x = x; p.ln_w = lnw; p.ln_b = lnb; launch_skinny(p, slabs, tick, st); }, (double)V * d * 2);
     }
+    {   // the same GEMVs on the tile-major repack of their weights
+        half_t *wt = dmalloc<half_t>((size_t)((V + 15) / 16) * 16 * d);
+        auto tiled = [&](const char *name, int reps, int N, int K, int epi, void *o0, long ldo, bool ln) {
+            half_t *Wr = W((size_t)N * K);
+            launch_repack_tiles(Wr, wt, N, K, st);
+            bench(name, reps, [&] {
+                SkinnyParams p{}; p.x = ln ? nullptr : (K == d ? xn : hid); p.ldx = K; p.W = Wr; p.Wt = wt; p.bias = epi == SK_F32 ? nullptr : bias; p.R = B; p.N = N; p.K = K; p.epi = epi;
+                p.out[0] = o0; p.out[1] = sk; p.out[2] = sv; p.ldo = ldo; p.d = d; p.t0 = 5; p.Tn = 1; p.ctx = C;
+                if (ln) { p.ln_x = x; p.ln_w = lnw; p.ln_b = lnb; }
+                launch_skinny(p, slabs, tick, st);
+            }, (double)N * K * 2);
+        };
+        tiled("tiled LN+qkv   N=3840 K=1280", R, 3 * d, d, SK_QKV, q, d, true);
+        tiled("tiled o        N=1280 K=1280 (RESID)", R, d, d, SK_RESID_F32, x, d, false);
+        tiled("tiled LN+fc1   N=5120 K=1280", R, 4 * d, d, SK_GELU_F16, hid, 4 * d, true);
+        tiled("tiled fc2      N=1280 K=5120 (RESID)", R, d, 4 * d, SK_RESID_F32, x, d, false);
+        tiled("tiled LN+logits N=51866 K=1280", 9, V, d, SK_F32, logits, VP, true);
+    }
     bench("layernorm (sliced) B rows", R, [&] { launch_layernorm_sliced(x, lnw, lnb, xn, nullptr, B, d, st); });
     bench("layernorm B rows", R, [&] { launch_layernorm(x, lnw, lnb, xn, nullptr, B, d, st); });
     bench("embed", R, [&] { launch_embed(ds.tokens, 4096, w_e, w_e, x, B, 1, 5, nullptr, d, st); });

@@ -61,6 +61,27 @@ __global__ __launch_bounds__(256) void stream_read(const f32x4 *__restrict__ p, 
     if (s[0] + s[1] + s[2] + s[3] == 1.2345f) out[0] = s[0];
 }
 
+// the logits GEMV's weight stream without the GEMV: 16-row tiles of a [V][1280] fp16 matrix, 10 loads of 16 B in flight per
+// lane.  TILED = 0: rows as stored (a wave instruction = 16 rows x 64 B, 2560 B apart); 1: tile-major repack (1 KiB contiguous)
+template <int TILED>
+__global__ __launch_bounds__(512) void gemv_stream(const half_t *__restrict__ W, int V, float *out) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, fr = lane & 15, fq = lane >> 4;
+    const int tiles = V / 16, nw = gridDim.x * 8;
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int tile = blockIdx.x * 8 + w; tile < tiles; tile += nw) {
+        const half_t *base = TILED ? W + (size_t)tile * 16 * 1280 + lane * 8 : W + ((size_t)tile * 16 + fr) * 1280 + 8 * fq;
+        for (int s0 = 0; s0 < 40; s0 += 10) {
+            f4 a[10];
+#pragma unroll
+            for (int u = 0; u < 10; u++) a[u] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(base + (TILED ? 512 : 32) * (s0 + u)));
+#pragma unroll
+            for (int u = 0; u < 10; u++) acc += a[u];
+        }
+    }
+    if (acc[0] + acc[1] + acc[2] + acc[3] == 1.2345f) out[0] = acc[0];
+}
+
 int main(int argc, char **argv) {
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -92,6 +113,22 @@ int main(int argc, char **argv) {
             printf("hbm read stream, %d blocks: %7.1f GB/s\n", blocks, bytes / (ms * 1e-3) / 1e9);
         }
         CK(hipFree(buf));
+    }
+    // ---- GEMV-shaped weight stream (the decode step's logits layer): stored rows vs tile-major repack
+    {
+        const int V = 51872; half_t *Wg; CK(hipMalloc(&Wg, (size_t)4 * V * 1280 * 2)); CK(hipMemset(Wg, 1, (size_t)4 * V * 1280 * 2));
+        for (int tiled = 0; tiled < 2; tiled++) {
+            for (int rep = 0; rep < 5; rep++) {
+                const half_t *Wr = Wg + (size_t)(rep % 4) * V * 1280;  // rotate over 4 copies: no Infinity-Cache reuse
+                hipEventRecord(e0, st);
+                if (tiled) hipLaunchKernelGGL(gemv_stream<1>, dim3(256), dim3(512), 0, st, Wr, V, out);
+                else hipLaunchKernelGGL(gemv_stream<0>, dim3(256), dim3(512), 0, st, Wr, V, out);
+                hipEventRecord(e1, st); CK(hipEventSynchronize(e1)); hipEventElapsedTime(&ms, e0, e1);
+            }
+            printf("gemv-shaped stream of 133 MB, %s: %6.1f us  %7.1f GB/s\n", tiled ? "tile-major (1 KiB per wave instruction)" : "stored rows (16 x 64 B per wave instruction)",
+                   ms * 1e3, (double)V * 1280 * 2 / (ms * 1e-3) / 1e9);
+        }
+        CK(hipFree(Wg));
     }
     // ---- vendor GEMM on the encoder shapes: C[M][N] (f16) = A[M][K] . W[N][K]^T, f32 accumulate
     {
