@@ -599,7 +599,8 @@ __device__ __forceinline__ void merge_part(AttnPart &a, float mo, float lo, cons
 
 __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict__ q, const half_t *__restrict__ kc,
                                                        const half_t *__restrict__ vc, half_t *__restrict__ out,
-                                                       int d, int ctx, int Tk, const int32_t *__restrict__ pos_ptr) {
+                                                       int d, int ctx, int Tk, const int32_t *__restrict__ pos_ptr,
+                                                       int kv_head_major) {
     if (pos_ptr) Tk = *pos_ptr + 1;
     __shared__ float part[4][8][10];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -614,8 +615,12 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict_
     // candle scales q and k by dh^-1/4 each; the product of the two scalings is exactly 1/8
     const int per = (((Tk + 3) >> 2) + 7) & ~7;  // keys per wave, multiple of 8
     const int kbeg = w * per, kend = min(Tk, kbeg + per);
-    const half_t *kb = kc + (long)b * ctx * d + h * NH_DH + 8 * pp;
-    const half_t *vb = vc + (long)b * ctx * d + h * NH_DH + 8 * pp;
+    // rows of one (clip, head): [b][ctx][d] (the self-attention cache, 128 B out of every d * 2) or head-major
+    // [b][h][ctx][64] (cross K/V: the keys of a head are contiguous, a wave instruction reads 1 KiB in one piece)
+    const long rs = kv_head_major ? NH_DH : d;
+    const long base = kv_head_major ? ((long)b * gridDim.x + h) * ctx * NH_DH : (long)b * ctx * d + h * NH_DH;
+    const half_t *kb = kc + base + 8 * pp;
+    const half_t *vb = vc + base + 8 * pp;
     AttnPart st; st.m = -INFINITY; st.l = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; c++) st.acc[c] = 0.f;
@@ -626,8 +631,8 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict_
             int j = j0 + 8 * u + slot; if (j >= kend) j = kend - 1;
             // streamed once per token: non-temporal, so the K/V stream (491 MB per step at b32) does not evict the
             // decoder weights from the Infinity Cache between tokens
-            kk[u] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(kb + (long)j * d));
-            vv[u] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(vb + (long)j * d));
+            kk[u] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(kb + j * rs));
+            vv[u] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(vb + j * rs));
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -681,9 +686,9 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict_
 }
 
 void launch_dec_attention(const half_t *q, const half_t *kc, const half_t *vc, half_t *out, int B, int Tn,
-                          int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st) {
+                          int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st, int kv_head_major) {
     (void)Tn;  // one new position per sequence; its visible keys are exactly Tk (or *pos_ptr + 1)
-    hipLaunchKernelGGL(dec_attn_kernel, dim3(H, B), dim3(256), 0, st, q, kc, vc, out, d, ctx, Tk, pos_ptr);
+    hipLaunchKernelGGL(dec_attn_kernel, dim3(H, B), dim3(256), 0, st, q, kc, vc, out, d, ctx, Tk, pos_ptr, kv_head_major);
 }
 
 // ---------------------------------------------------------------------------------------------------

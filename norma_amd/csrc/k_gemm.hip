@@ -226,7 +226,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
                     v[0] = gelu_tanh_f(v[0]); v[1] = gelu_tanh_f(v[1]);
                     v[2] = gelu_tanh_f(v[2]); v[3] = gelu_tanh_f(v[3]);
                 }
-                half_t *dst = obase + out_row(p, m) * p.ldo + (n - seg * p.seg_n);
+                const int nl = n - seg * p.seg_n;
+                half_t *dst = p.head_major ? obase + (((long)(m / p.S) * p.H + (nl >> 6)) * p.S + m % p.S) * NH_DH + (nl & 63)
+                                           : obase + out_row(p, m) * p.ldo + nl;
                 half4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 *reinterpret_cast<half4 *>(dst) = hv;
             } else if (p.epi == EPI_RESID_F32) {
@@ -565,7 +567,10 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmParams p) {
                     const half4 hi = *reinterpret_cast<const half4 *>(img + mr * PP_EPI_PITCH + (lane & 7) * 16 + 8);
                     if (m < p.M && (!(G2_ABL & 32) || lo[0] == (half_t)123.456f)) {
                         half8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        *reinterpret_cast<half8 *>(ob + out_row(p, m) * p.ldo + ncol) = o;
+                        // head-major: the wave's 64 columns are one head (seg_n and the tile base are multiples of 64)
+                        half_t *dst = p.head_major ? ob + (((long)(m / p.S) * p.H + (ncol >> 6)) * p.S + m % p.S) * NH_DH + (lane & 7) * 8
+                                                   : ob + out_row(p, m) * p.ldo + ncol;
+                        *reinterpret_cast<half8 *>(dst) = o;
                     }
                 }
             }

@@ -582,8 +582,9 @@ static void gemm_prof_end(nh_ctx *ctx, const GemmParams &p) {
 }
 
 static void gemm_plain(nh_ctx *ctx, const half_t *A, long lda, const LinW &W, int M, int N, int K, int epi, void *o0,
-                       void *o1, void *o2, int seg_n, long ldo, int vt_seg) {
+                       void *o1, void *o2, int seg_n, long ldo, int vt_seg, int head_major = 0) {
     GemmParams p{};
+    p.head_major = head_major;
     p.A = A; p.lda = lda; p.a_rpb = M; p.a_bstride = 0; p.W = W.w; p.bias = W.b; p.M = M; p.N = N; p.K = K; p.epi = epi;
     p.out[0] = o0; p.out[1] = o1; p.out[2] = o2; p.seg_n = seg_n; p.ldo = ldo; p.o_rpb = M; p.o_bstride = 0; p.o_off = 0;
     p.vt_seg = vt_seg; p.S = ctx->S; p.H = ctx->c.encoder_attention_heads; p.pos = nullptr;
@@ -630,7 +631,7 @@ extern "C" int nh_encode(nh_ctx *ctx) {
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->st));
     // cross-attention K/V of every decoder layer (the flush = true work of MultiHeadAttention::forward)
     for (auto &L : ctx->dec)
-        gemm_plain(ctx, ctx->xa16, d, L.ckv, M, 2 * d, d, EPI_F16, L.ck, L.cv, nullptr, d, d, -1);
+        gemm_plain(ctx, ctx->xa16, d, L.ckv, M, 2 * d, d, EPI_F16, L.ck, L.cv, nullptr, d, d, -1, 1);  // [b][h][S][64]
     HIPCHK(hipEventRecord(ctx->ev[4], ctx->st));
     HIPCHK(hipEventRecord(ctx->enc_done, ctx->st));
     HIPCHK(hipGetLastError());
@@ -689,7 +690,7 @@ static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr,
         launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos_ptr, ctx->sd);
         skinny(ctx, ctx->datt, d, L.o, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
         ln_skinny(ctx, L.ln2, L.cq, B, d, d, SK_F16, ctx->dq, nullptr, nullptr, d, 0, C, nullptr);
-        launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, nullptr, ctx->sd);
+        launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, nullptr, ctx->sd, 1);  // head-major cross K/V
         skinny(ctx, ctx->datt, d, L.co, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
         ln_skinny(ctx, L.ln3, L.fc1, B, 4 * d, d, SK_GELU_F16, ctx->dhid, nullptr, nullptr, 4 * d, 0, C, nullptr);
         skinny(ctx, ctx->dhid, 4 * d, L.fc2, B, d, 4 * d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);

@@ -33,6 +33,8 @@ struct GemmParams {
     void *out[3]; int seg_n; long ldo;          // EPI_F16*: column segment s = n / seg_n goes to out[s]
     int o_rpb; long o_bstride; long o_off;      // output row = (m/o_rpb)*o_bstride + (m%o_rpb) + o_off
     int vt_seg;                                 // segment written as V^T [b][h][64][SP] (or -1)
+    int head_major;                             // EPI_F16: every segment is written [b][h][S][64] (clip b = m / S, 64-wide head h)
+                                                // instead of [m][seg_n]: the decoder streams cross K/V per (clip, head)
     int S, H;                                   // rows per clip / heads (V^T and conv2 epilogues)
     const float *pos;                           // conv2: positional embedding [S][N]
 };
@@ -168,8 +170,9 @@ void launch_enc_attention(const half_t *q, const half_t *k, long ld, const half_
 // ---- decoder attention (one query row per (b, h, i)) -------------------------------------------------
 // q: fp16 [B*Tn][d]; kc,vc: fp16 [B][ctx][d]; keys visible to new row i: t0 + i + 1 (causal) or Tk (cross)
 // pos_ptr != nullptr: causal self-attention over *pos_ptr + 1 keys (device-side position)
+// kv_head_major: K/V are [b][h][ctx][64] (the cross K/V written with GemmParams::head_major) instead of [b][ctx][d]
 void launch_dec_attention(const half_t *q, const half_t *kc, const half_t *vc, half_t *out, int B, int Tn,
-                          int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st);
+                          int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st, int kv_head_major = 0);
 
 // ---- logit processor: softmax + norma rules + argmax + bookkeeping -----------------------------------
 struct DecodeState {        // all device pointers

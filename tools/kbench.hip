@@ -97,6 +97,7 @@ int main(int argc, char **argv) {
     bench("skinny logits N=51866 K=1280 (F32)", 9, [&] { SkinnyParams p{}; p.x = xn; p.ldx = d; p.W = W((size_t)V * d); p.R = B; p.N = V; p.K = d; p.epi = SK_F32; p.out[0] = logits; p.ldo = VP; launch_skinny(p, slabs, tick, st); }, (double)V * d * 2);
     bench("dec_attn self Tk=200", R, [&] { launch_dec_attention(q, sk, sv, att, B, 1, H, d, C, 200, nullptr, st); }, 2.0 * B * 200 * d * 2);
     bench("dec_attn cross Tk=1500", 9, [&] { size_t o = (size_t)(kvr++ % 3) * B * S * d; launch_dec_attention(q, kc + o, vc + o, att, B, 1, H, d, S, S, nullptr, st); }, 2.0 * B * S * d * 2);
+    bench("dec_attn cross Tk=1500, head-major K/V", 9, [&] { size_t o = (size_t)(kvr++ % 3) * B * S * d; launch_dec_attention(q, kc + o, vc + o, att, B, 1, H, d, S, S, nullptr, st, 1); }, 2.0 * B * S * d * 2);
     bench("logit_step mode 1", R, [&] { launch_logit_step(logits, V, ds, tk, B, 4096, 1 << 30, 0, 3, 1, lpart, ltick, nullptr, st); }, (double)B * V * 4);
     return 0;
 }
