@@ -59,7 +59,9 @@ __device__ __forceinline__ void skinny_store(const SkinnyParams &p, f32x4 v, int
         if (sg == 0) dst = reinterpret_cast<half_t *>(p.out[0]) + (long)r * p.d + nl;
         else {
             const int t0 = p.pos_ptr ? *p.pos_ptr : p.t0;
-            dst = reinterpret_cast<half_t *>(sg == 1 ? p.out[1] : p.out[2]) + ((long)b * p.ctx + t0 + i) * p.d + nl;
+            // self-attention K/V cache, head-major [b][h][ctx][64]: the keys of one (clip, head) are contiguous for dec_attn_kernel
+            dst = reinterpret_cast<half_t *>(sg == 1 ? p.out[1] : p.out[2]) +
+                  (((long)b * (p.d >> 6) + (nl >> 6)) * p.ctx + t0 + i) * NH_DH + (nl & 63);
         }
         *reinterpret_cast<half4 *>(dst) = hv;
         return;

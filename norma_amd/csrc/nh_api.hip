@@ -687,7 +687,7 @@ static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr,
     launch_embed(ctx->ds.tokens, C, ctx->tok_emb, ctx->dec_pos, ctx->dx, B, 1, pos, pos_ptr, d, ctx->sd);
     for (auto &L : ctx->dec) {
         ln_skinny(ctx, L.ln1, L.qkv, B, 3 * d, d, SK_QKV, ctx->dq, L.sk, L.sv, d, pos, C, pos_ptr);
-        launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos_ptr, ctx->sd);
+        launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos_ptr, ctx->sd, 1);  // head-major cache
         skinny(ctx, ctx->datt, d, L.o, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
         ln_skinny(ctx, L.ln2, L.cq, B, d, d, SK_F16, ctx->dq, nullptr, nullptr, d, 0, C, nullptr);
         launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, nullptr, ctx->sd, 1);  // head-major cross K/V

@@ -55,7 +55,7 @@ struct SkinnyParams {
     int R, N, K;
     int epi;
     void *out[3]; long ldo;
-    // SK_QKV: row r = b*Tn + i  (Tn new positions per sequence); cache row = (b*ctx + t0 + i)
+    // SK_QKV: row r = b*Tn + i  (Tn new positions per sequence); k, v go to the head-major caches [b][h][ctx][64] at t0 + i
     int d, t0, Tn, ctx;
     const int32_t *pos_ptr;  // when set, t0 is read from device memory (hipGraph replay of the decode step)
     // LayerNorm fused into the activation load (skinny_ln_supported): x is ignored, the activations are
