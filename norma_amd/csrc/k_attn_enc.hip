@@ -128,8 +128,12 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const half_t *__restri
         }
         l_run = l_run * alpha + ps;
         m_run = m_new;
+        // the running maximum settles after the first tiles: when no query of the wave moved it, alpha is exactly 1 and the
+        // 32 rescaling multiplies (VALU is what bounds this kernel) are skipped -- bit-identical either way
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-        for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+            for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
         // P^T fragments (B operand): k-step (blk, s2) takes accumulator registers 8 s2 .. 8 s2 + 7
         half8 p00, p01, p10, p11;
 #pragma unroll
