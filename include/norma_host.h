@@ -30,6 +30,10 @@ extern "C" {
 #define NM_MODEL_DISTIL_MEDIUM_EN 4
 #define NM_MODEL_DISTIL_LARGE_EN_V2 5
 #define NM_MODEL_DISTIL_LARGE_EN_V3 6
+/* the q8_0 GGUF checkpoints of lmz/candle-whisper (monolingual QuantizedTinyEn, multilingual QuantizedTiny): loaded from
+ * config-{ext}.json / tokenizer-{ext}.json / model-{ext}-q80.gguf, ext = "tiny-en" / "tiny"; weights are dequantised at load */
+#define NM_MODEL_QUANTIZED_TINY_EN 7
+#define NM_MODEL_QUANTIZED_TINY 8
 
 typedef struct nm_definition nm_definition; /* whisper::monolingual::Definition */
 typedef struct nm_model nm_model;           /* whisper::Model */
@@ -59,6 +63,9 @@ nm_model *nm_definition_blocking_try_to_model_from_dir(const nm_definition *d, c
  * (languages.rs:7-107); the language is inferred on the first slice and cleared on final_chunk.
  * (nm_definition_blocking_try_to_model_from_dir enables it itself when `language` is NULL or "".) */
 void nm_model_enable_language_detection(nm_model *m, const int32_t *lang_tokens, int n);
+/* GGUF reader check (no GPU needed): writes one line per tensor "name type d0xd1.. sum_of_dequantised_values\n" into buf,
+ * returns the number of tensors or -1 (message in buf). */
+int nm_gguf_list(const char *path, char *buf, int cap);
 int nm_model_language_token(const nm_model *m); /* current language token, -1 = not detected yet */
 /* decode_with_fallback's sampled attempts at t = 0.2 .. 1.0 (model.rs:175-188).  Off by default: the t = 0 result is
  * returned and nm_model_last_result reports needed_fallback.  On: the reference's loop, drawing under the seeded

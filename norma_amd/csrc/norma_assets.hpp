@@ -193,6 +193,100 @@ class SafeTensors {
     MappedFile f_;
 };
 
+// ---- GGUF (v2 / v3): the quantised checkpoints of `lmz/candle-whisper` (model-tiny-q80.gguf, model-tiny-en-q80.gguf) that
+// multilingual.rs:195-199, 227-232 / monolingual.rs load through candle's quantized_var_builder::VarBuilder::from_gguf.
+// Layout: "GGUF", u32 version, u64 n_tensors, u64 n_kv; n_kv x {string key, u32 type, value}; n_tensors x {string name,
+// u32 n_dims, u64 dims[] (innermost first), u32 ggml type, u64 offset}; padding to general.alignment (default 32); data.
+// Tensor types read here: F32 (0), F16 (1), Q8_0 (8: blocks of 32 int8 preceded by one f16 scale, 34 bytes).
+// The MI355X path keeps no int8 arithmetic: weights are dequantised at load time (value = scale * q, then rounded to
+// fp16 like every other weight) and run through the same fp16 MFMA kernels.  candle's CPU path for these models also
+// quantises the ACTIVATIONS of every matmul to Q8_0 blocks (k_quants vec_dot_q8_0_q8_0); that is a property of its CPU
+// kernels, not of the checkpoint, and is not reproduced (its own CUDA path does not do it either).
+struct GgufTensor { std::string name; uint32_t type = 0; std::vector<int64_t> shape /* outermost first */; const char *data = nullptr; size_t n_elem = 0; };
+
+class GgufFile {
+  public:
+    bool open(const std::string &path, std::string &err) {
+        if (!f_.open(path, err)) return false;
+        p_ = f_.data(); end_ = p_ + f_.size();
+        uint32_t magic = 0, version = 0; uint64_t n_tensors = 0, n_kv = 0;
+        if (!rd(magic) || magic != 0x46554747u) { err = "gguf: bad magic in " + path; return false; }
+        if (!rd(version) || version < 2 || version > 3) { err = "gguf: unsupported version " + std::to_string(version); return false; }
+        if (!rd(n_tensors) || !rd(n_kv) || n_tensors > (1u << 20) || n_kv > (1u << 20)) { err = "gguf: bad header"; return false; }
+        uint64_t alignment = 32;
+        for (uint64_t i = 0; i < n_kv; i++) {
+            std::string key; uint32_t vt = 0;
+            if (!rd_str(key) || !rd(vt)) { err = "gguf: truncated metadata"; return false; }
+            uint64_t as_u64 = 0; bool have_u = false;
+            if (!skip_value(vt, 0, &as_u64, &have_u)) { err = "gguf: bad metadata value for " + key; return false; }
+            if (key == "general.alignment" && have_u && as_u64 > 0) alignment = as_u64;
+        }
+        std::vector<uint64_t> offs;
+        for (uint64_t i = 0; i < n_tensors; i++) {
+            GgufTensor t; uint32_t nd = 0; uint64_t off = 0;
+            if (!rd_str(t.name) || !rd(nd) || nd > 4) { err = "gguf: truncated tensor info"; return false; }
+            std::vector<uint64_t> ne(nd);
+            t.n_elem = 1;
+            for (uint32_t d = 0; d < nd; d++) { if (!rd(ne[d])) { err = "gguf: truncated dims"; return false; } t.n_elem *= (size_t)ne[d]; }
+            for (uint32_t d = 0; d < nd; d++) t.shape.push_back((int64_t)ne[nd - 1 - d]);   // ggml lists the contiguous dim first
+            if (!rd(t.type) || !rd(off)) { err = "gguf: truncated tensor info"; return false; }
+            if (t.type == 8 && (nd == 0 || ne[0] % 32 != 0)) { err = "gguf: Q8_0 tensor " + t.name + " with a row length that is not a multiple of 32"; return false; }
+            offs.push_back(off);
+            tensors.push_back(std::move(t));
+        }
+        const size_t hdr = (size_t)(p_ - f_.data());
+        const size_t base = (hdr + alignment - 1) / alignment * alignment;
+        for (size_t i = 0; i < tensors.size(); i++) {
+            GgufTensor &t = tensors[i];
+            size_t bytes;
+            if (t.type == 0) bytes = t.n_elem * 4;
+            else if (t.type == 1) bytes = t.n_elem * 2;
+            else if (t.type == 8) bytes = t.n_elem / 32 * 34;
+            else { err = "gguf: unsupported ggml type " + std::to_string(t.type) + " for " + t.name; return false; }
+            if (base + offs[i] + bytes > f_.size()) { err = "gguf: data of " + t.name + " runs past the end of the file"; return false; }
+            t.data = f_.data() + base + offs[i];
+        }
+        return true;
+    }
+    // f32 copy of a tensor (Q8_0: scale * q per 32-block)
+    static void to_f32(const GgufTensor &t, std::vector<float> &out) {
+        out.resize(t.n_elem);
+        if (t.type == 0) memcpy(out.data(), t.data, t.n_elem * 4);
+        else if (t.type == 1) { const _Float16 *h = reinterpret_cast<const _Float16 *>(t.data); for (size_t i = 0; i < t.n_elem; i++) out[i] = (float)h[i]; }
+        else {
+            const char *b = t.data;
+            for (size_t blk = 0; blk < t.n_elem / 32; blk++, b += 34) {
+                _Float16 d; memcpy(&d, b, 2);
+                const float scale = (float)d;
+                const int8_t *q = reinterpret_cast<const int8_t *>(b + 2);
+                for (int j = 0; j < 32; j++) out[blk * 32 + j] = scale * (float)q[j];
+            }
+        }
+    }
+    std::vector<GgufTensor> tensors;
+
+  private:
+    template <typename T> bool rd(T &v) { if ((size_t)(end_ - p_) < sizeof(T)) return false; memcpy(&v, p_, sizeof(T)); p_ += sizeof(T); return true; }
+    bool rd_str(std::string &s) { uint64_t n = 0; if (!rd(n) || n > (size_t)(end_ - p_)) return false; s.assign(p_, (size_t)n); p_ += n; return true; }
+    bool skip_value(uint32_t vt, int depth, uint64_t *as_u64, bool *have_u) {
+        static const int sz[] = {1, 1, 2, 2, 4, 4, 4, 1, -1, -2, 8, 8, 8};  // u8 i8 u16 i16 u32 i32 f32 bool string array u64 i64 f64
+        if (vt > 12) return false;
+        if (sz[vt] > 0) {
+            if ((size_t)(end_ - p_) < (size_t)sz[vt]) return false;
+            if (as_u64 && (vt == 4 || vt == 10)) { uint64_t v = 0; memcpy(&v, p_, (size_t)sz[vt]); *as_u64 = v; *have_u = true; }
+            p_ += sz[vt];
+            return true;
+        }
+        if (vt == 8) { std::string s; return rd_str(s); }
+        uint32_t et = 0; uint64_t n = 0;
+        if (depth > 2 || !rd(et) || !rd(n)) return false;
+        for (uint64_t i = 0; i < n; i++) if (!skip_value(et, depth + 1, nullptr, nullptr)) return false;
+        return true;
+    }
+    MappedFile f_;
+    const char *p_ = nullptr, *end_ = nullptr;
+};
+
 // ---- config.json: the fields candle's Config reads -------------------------------------------
 struct ConfigJson {
     int num_mel_bins = 0, max_source_positions = 0, d_model = 0, encoder_attention_heads = 0, encoder_layers = 0,

@@ -89,6 +89,22 @@ int nm_model_transcribe(nm_model *m, const float *data, size_t n, int final_chun
     return 0;
 }
 
+int nm_gguf_list(const char *path, char *buf, int cap) {
+    norma::assets::GgufFile g; std::string err;
+    if (!path || !g.open(path, err)) { put_err(buf, cap, err.empty() ? "nm_gguf_list: no path" : err); return -1; }
+    std::string out;
+    for (const auto &t : g.tensors) {
+        std::vector<float> v; norma::assets::GgufFile::to_f32(t, v);
+        double s = 0; for (float x : v) s += x;
+        out += t.name + " " + std::to_string(t.type) + " ";
+        for (size_t i = 0; i < t.shape.size(); i++) out += (i ? "x" : "") + std::to_string(t.shape[i]);
+        char num[64]; snprintf(num, sizeof num, " %.9g\n", s);
+        out += num;
+    }
+    put_err(buf, cap, out);
+    return (int)g.tensors.size();
+}
+
 void nm_model_set_temperature_fallback(nm_model *m, int enable, uint64_t seed) {
     if (m && m->m) m->m->set_temperature_fallback(enable != 0, seed);
 }

@@ -94,13 +94,18 @@ struct Error {
 enum class VocabVersion { V1, V2, EnV1, EnV2 };  // whisper/mod.rs:57-62
 
 // monolingual.rs:32-46 (ids/revisions are download metadata, out of scope offline)
-enum class ModelType { TinyEn, BaseEn, SmallEn, MediumEn, DistilMediumEn, DistilLargeEnV2, DistilLargeEnV3 };
-inline VocabVersion vocab_version(ModelType m) {  // monolingual.rs:99-110
+enum class ModelType { TinyEn, BaseEn, SmallEn, MediumEn, DistilMediumEn, DistilLargeEnV2, DistilLargeEnV3,
+                       QuantizedTinyEn, QuantizedTiny };  // the q8_0 GGUF checkpoints (monolingual.rs:32-46, multilingual.rs:37-49)
+inline VocabVersion vocab_version(ModelType m) {  // monolingual.rs:99-110, multilingual.rs:73-84
     switch (m) {
-        case ModelType::DistilMediumEn: case ModelType::DistilLargeEnV2: return VocabVersion::V1;
+        case ModelType::DistilMediumEn: case ModelType::DistilLargeEnV2: case ModelType::QuantizedTiny: return VocabVersion::V1;
         case ModelType::DistilLargeEnV3: return VocabVersion::V2;
         default: return VocabVersion::EnV1;
     }
+}
+// multilingual.rs:87-92 / the monolingual twin: file-name infix of the quantised checkpoints, nullptr for the others
+inline const char *quantized_ext(ModelType m) {
+    return m == ModelType::QuantizedTiny ? "tiny" : m == ModelType::QuantizedTinyEn ? "tiny-en" : nullptr;
 }
 
 // whisper::Language (languages.rs:7-107): the 99 languages in `Language::iter()` order; token = "<|code|>" (:119-222)
@@ -290,10 +295,13 @@ class Definition {
                                          const std::string &language = "<|en|>", bool translate = false,
                                          bool detect_language = false) const {
         std::string err;
+        // quantised models: config-{ext}.json / tokenizer-{ext}.json / model-{ext}-q80.gguf (multilingual.rs:195-199)
+        const char *qext = quantized_ext(model_);
+        const std::string sfx = qext ? std::string("-") + qext : std::string();
         assets::ConfigJson cj;
-        if (!cj.load(dir + "/config.json", err)) return Error{Error::Backend, err};
+        if (!cj.load(dir + "/config" + sfx + ".json", err)) return Error{Error::Backend, err};
         auto tok = std::make_shared<assets::TokenizerJson>();
-        if (!tok->load(dir + "/tokenizer.json", err)) return Error{Error::Backend, err};
+        if (!tok->load(dir + "/tokenizer" + sfx + ".json", err)) return Error{Error::Backend, err};
         auto id = [&](const char *t, int &dst) { dst = tok->token_to_id(t); return dst >= 0; };
         nh_tokens tk{};
         // candle constants m::SOT_TOKEN, EOT_TOKEN, TRANSCRIBE_TOKEN, TRANSLATE_TOKEN, NO_TIMESTAMPS_TOKEN, NO_SPEECH_TOKENS
@@ -314,14 +322,25 @@ class Definition {
         if (!id("<|0.00|>", tk.zero_sec)) return Error{Error::TokenId, "Failed to get token ID for: <|0.00|>"};
         if (!id("<|1.00|>", tk.one_sec)) return Error{Error::TokenId, "Failed to get token ID for: <|1.00|>"};
         assets::SafeTensors st;
-        if (!st.open(dir + "/model.safetensors", err)) return Error{Error::Backend, err};
+        assets::GgufFile gg;
+        std::vector<std::vector<float>> deq;   // dequantised GGUF tensors (kept alive until the upload below)
         std::vector<TensorView> tv;
-        for (const auto &t : st.tensors) {
-            int dt;
-            if (t.dtype == "F16") dt = NH_DTYPE_F16;
-            else if (t.dtype == "F32") dt = NH_DTYPE_F32;
-            else return Error{Error::Backend, "model.safetensors: unsupported dtype " + t.dtype + " for " + t.name};
-            tv.push_back(TensorView{t.name, dt, t.shape, t.data});
+        if (qext) {
+            if (!gg.open(dir + "/model-" + qext + "-q80.gguf", err)) return Error{Error::Backend, err};
+            deq.resize(gg.tensors.size());
+            for (size_t i = 0; i < gg.tensors.size(); i++) {
+                assets::GgufFile::to_f32(gg.tensors[i], deq[i]);
+                tv.push_back(TensorView{gg.tensors[i].name, NH_DTYPE_F32, gg.tensors[i].shape, deq[i].data()});
+            }
+        } else {
+            if (!st.open(dir + "/model.safetensors", err)) return Error{Error::Backend, err};
+            for (const auto &t : st.tensors) {
+                int dt;
+                if (t.dtype == "F16") dt = NH_DTYPE_F16;
+                else if (t.dtype == "F32") dt = NH_DTYPE_F32;
+                else return Error{Error::Backend, "model.safetensors: unsupported dtype " + t.dtype + " for " + t.name};
+                tv.push_back(TensorView{t.name, dt, t.shape, t.data});
+            }
         }
         nh_config cfg{cj.num_mel_bins, cj.max_source_positions, cj.d_model, cj.encoder_attention_heads, cj.encoder_layers,
                       cj.vocab_size, cj.max_target_positions, cj.decoder_attention_heads, cj.decoder_layers};

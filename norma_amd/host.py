@@ -53,6 +53,11 @@ class ModelType(enum.IntEnum):
     DistilMediumEn = 4
     DistilLargeEnV2 = 5
     DistilLargeEnV3 = 6
+    QuantizedTinyEn = 7     # q8_0 GGUF checkpoint (monolingual.rs), files *-tiny-en*
+    QuantizedTiny = 8       # q8_0 GGUF checkpoint (multilingual.rs:49), files *-tiny*
+
+
+QUANTIZED_EXT = {ModelType.QuantizedTinyEn: "tiny-en", ModelType.QuantizedTiny: "tiny"}
 
 
 class WhisperError(RuntimeError):
@@ -89,6 +94,7 @@ def _lib():
         L.nm_model_last_text.argtypes = [vp, C.c_char_p, C.c_int]
         L.nm_model_enable_language_detection.argtypes = [vp, C.POINTER(C.c_int32), C.c_int]
         L.nm_model_language_token.argtypes = [vp]
+        L.nm_gguf_list.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
         L.nm_model_set_temperature_fallback.argtypes = [vp, C.c_int, C.c_uint64]
         L.nm_model_free.argtypes = [vp]
         L.nm_model_transcribe.argtypes = [vp, C.POINTER(C.c_float), C.c_size_t, C.c_int, C.POINTER(C.c_int32), C.c_int,
@@ -167,6 +173,20 @@ class Model:
         return dict(avg_logprob=a.value, no_speech_prob=n.value, needed_fallback=bool(f.value), n_tokens=k.value)
 
 
+def gguf_list(path: str):
+    """Tensors of a GGUF file as the C++ reader sees them: [(name, ggml_type, shape, sum of dequantised values)]."""
+    _lib()
+    buf = C.create_string_buffer(1 << 20)
+    n = _lib().nm_gguf_list(path.encode(), buf, len(buf))
+    if n < 0:
+        raise WhisperError(buf.value.decode())
+    out = []
+    for line in buf.value.decode().splitlines():
+        name, ty, shape, s = line.split(" ")
+        out.append((name, int(ty), tuple(int(x) for x in shape.split("x")), float(s)))
+    return out
+
+
 class Definition:
     """whisper::monolingual::Definition (monolingual.rs:113-174)."""
 
@@ -204,7 +224,8 @@ class Definition:
         detected (multilingual.rs:463-466)."""
         import json
         import os
-        with open(os.path.join(path, "config.json")) as f:
+        ext = QUANTIZED_EXT.get(self.model)   # quantised checkpoints: config-{ext}.json, tokenizer-{ext}.json, model-{ext}-q80.gguf
+        with open(os.path.join(path, f"config-{ext}.json" if ext else "config.json")) as f:
             n_mel = json.load(f)["num_mel_bins"]
         filt = np.ascontiguousarray(assets_io.mel_filters(n_mel), dtype=np.float32)
         err = C.create_string_buffer(512)

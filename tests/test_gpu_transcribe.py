@@ -152,3 +152,41 @@ def test_local_checkpoint_directory_loads_and_yields_text(tmp_path):
     json.dump(tj, open(os.path.join(tmp_path, "tokenizer.json"), "w"))
     with pytest.raises(host.WhisperError, match="Failed to get token ID for: <|notimestamps|>".replace("|", r"\|")):
         d.blocking_try_to_model_from_dir(str(tmp_path))
+
+
+def test_quantized_q8_0_gguf_checkpoint_loads_and_transcribes(tmp_path):
+    """§8(f)-4, the part that needs no Rust: ModelType::QuantizedTinyEn reads config-tiny-en.json / tokenizer-tiny-en.json /
+    model-tiny-en-q80.gguf (the file names of monolingual.rs / multilingual.rs:195-199), dequantises the Q8_0 matrices and runs
+    the ordinary fp16 path.  Expected = the same model built by handing over the dequantised tensors directly, and the oracle
+    fed with those tensors.  (candle's CPU kernels for these checkpoints also quantise activations; that is not reproduced.)"""
+    import json
+    import os
+    import gguf_writer
+    name = "test-d128"
+    cfg = config.preset(name)
+    tk = common.tokens_for(name)
+    script = common.transcript_script(tk, n_segments=3, words_per_segment=4)
+    over = common.scripted_overrides(cfg, tk, script)
+    words = _write_checkpoint_dir(str(tmp_path), cfg, tk, synth.synth_weights(cfg, 0, over))
+    os.rename(tmp_path / "config.json", tmp_path / "config-tiny-en.json")
+    os.rename(tmp_path / "tokenizer.json", tmp_path / "tokenizer-tiny-en.json")
+    os.remove(tmp_path / "model.safetensors")
+    deq = gguf_writer.write_gguf(str(tmp_path / "model-tiny-en-q80.gguf"), synth.synth_weights(cfg, 0, over))
+    deq16 = {n: a.astype(np.float16) for n, a in deq.items()}          # what the loader uploads (fp16 like every weight)
+    d = host.Definition(host.ModelType.QuantizedTinyEn, host.SelectedDevice.Rocm(0))
+    model = d.blocking_try_to_model_from_dir(str(tmp_path))
+    pcm = synth.synth_pcm(0)
+    segs = model.transcribe(pcm, final_chunk=True)
+    ref_model = d.blocking_try_to_model(cfg, tk, tk.en, tk.transcribe, ((n, deq16[n]) for n, _ in synth.synth_weights(cfg, 0, over)))
+    assert segs == ref_model.transcribe(pcm, final_chunk=True)
+    om = common.oracle_module().OracleModel(cfg, tk, tk.en, tk.transcribe)
+    for n, _ in synth.synth_weights(cfg, 0, over):
+        om.set_tensor(n, deq16[n].astype(np.float32))
+    ref, buf, info = om.transcribe(pcm, assets_io.mel_filters(cfg.num_mel_bins), final_chunk=True)
+    assert segs == ref and len(segs) == 3          # 8-bit weights still follow the scripted transcript
+    assert abs(model.last_result()["avg_logprob"] - info["avg_logprob"]) < 5e-3
+    assert model.last_text() == "".join("".join(f" w{t}" for t in s) for s in segs)
+    model.close(); ref_model.close()
+    os.remove(tmp_path / "model-tiny-en-q80.gguf")
+    with pytest.raises(host.WhisperError, match="cannot open"):
+        d.blocking_try_to_model_from_dir(str(tmp_path))
