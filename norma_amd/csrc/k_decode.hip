@@ -527,10 +527,12 @@ static bool ln_steps_ok(int K) {
     return K % 128 == 0 && (s == 1 || s == 2 || s == 3 || s == 4 || s == 6 || s == 8 || s == 10);
 }
 static bool logits_lds_ok(int R, int N, int K) {
-    return (N + 15) / 16 >= 2048 && R <= 32 && (size_t)(K >> 5) * 16 * ((R + 15) / 16) * 64 <= 96 * 1024 && !getenv("NORMA_SK_LOGITS_NT");
+    static const bool nt_env = getenv("NORMA_SK_LOGITS_NT") != nullptr;
+    return (N + 15) / 16 >= 2048 && R <= 32 && (size_t)(K >> 5) * 16 * ((R + 15) / 16) * 64 <= 96 * 1024 && !nt_env;
 }
 bool skinny_ln_supported(int R, int N, int K) {
-    if (getenv("NORMA_HIP_NO_LN_FUSION")) return false;  // A/B switch
+    static const bool off = getenv("NORMA_HIP_NO_LN_FUSION") != nullptr;  // A/B switch
+    if (off) return false;
     if (R > 32) return false;
     if ((N + 15) / 16 >= 2048) return logits_lds_ok(R, N, K) && K <= 128 * LN_MAX_STEPS && K % 128 == 0;
     return ln_steps_ok(K);
