@@ -33,10 +33,6 @@ __device__ __forceinline__ const half_t *a_row_ptr(const GemmParams &p, int m) {
     return p.A + (long)b * p.a_bstride + (long)r * p.lda;
 }
 
-#ifndef NH_GEMM_GLDS
-#define NH_GEMM_GLDS 1  // 1: global_load_lds_dwordx4 straight into LDS; 0: stage through registers + ds_write_b128
-#endif
-
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
@@ -69,7 +65,6 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams &p, char *smem, i
         offA[j] = rowA * 128 + ((fq ^ ((rowA >> 1) & 7)) << 4);
         offB[j] = rowB * 128 + ((fq ^ ((rowB >> 1) & 7)) << 4);
     }
-#if NH_GEMM_GLDS
     const int wbase = __builtin_amdgcn_readfirstlane(w) * 1024;  // this wave's 1 KiB run inside each 4 KiB group
     auto stage = [&](int buf, int t) {
         char *la = smem + buf * 2 * TILE_BYTES + wbase, *lb = la + TILE_BYTES;
@@ -82,34 +77,10 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams &p, char *smem, i
     stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-#else
-    u32x4 ra[4], rb[4];
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        ra[i] = *reinterpret_cast<const u32x4 *>(ag[i]);
-        rb[i] = *reinterpret_cast<const u32x4 *>(wg[i]);
-    }
-    {
-        u32x4 *la = reinterpret_cast<u32x4 *>(smem), *lb = reinterpret_cast<u32x4 *>(smem + TILE_BYTES);
-#pragma unroll
-        for (int i = 0; i < 4; i++) { la[tid + 256 * i] = ra[i]; lb[tid + 256 * i] = rb[i]; }
-    }
-    __syncthreads();
-#endif
     int cur = 0;
     for (int t = 0; t < nt; t++) {
         const bool more = (t + 1 < nt);
-#if NH_GEMM_GLDS
         if (more) stage(cur ^ 1, t + 1);  // all waves left buf[cur^1] at the barrier that ended iteration t-1
-#else
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                ra[i] = *reinterpret_cast<const u32x4 *>(ag[i] + (long)(t + 1) * BK);
-                rb[i] = *reinterpret_cast<const u32x4 *>(wg[i] + (long)(t + 1) * BK);
-            }
-        }
-#endif
         const char *ta = smem + cur * 2 * TILE_BYTES, *tb = ta + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ks++) {
@@ -131,16 +102,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams &p, char *smem, i
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[j], fb[i], acc[i][j], 0, 0, 0);
                 }
         }
-#if NH_GEMM_GLDS
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA for tile t+1 has landed
-#else
-        if (more) {
-            u32x4 *la = reinterpret_cast<u32x4 *>(smem + (cur ^ 1) * 2 * TILE_BYTES);
-            u32x4 *lb = reinterpret_cast<u32x4 *>(smem + (cur ^ 1) * 2 * TILE_BYTES + TILE_BYTES);
-#pragma unroll
-            for (int i = 0; i < 4; i++) { la[tid + 256 * i] = ra[i]; lb[tid + 256 * i] = rb[i]; }
-        }
-#endif
         __syncthreads();
         cur ^= 1;
     }
