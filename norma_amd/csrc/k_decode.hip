@@ -240,31 +240,11 @@ __global__ __launch_bounds__(256) void skinny_ln_kernel(SkinnyParams p) {
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) {
         int r = 16 * cb + fr; if (r >= p.R) r = p.R - 1;
-        if (p.emb_tokens) {
-            // first decoder layer: the rows are token_embedding(x) + positional_embedding (embed_kernel's arithmetic), built
-            // here instead of by a launch of their own; workgroup 0 also stores them as the residual stream for the layers
-            // that follow (every wave holds its K-slice of every row)
-            const int t0 = p.pos_ptr ? *p.pos_ptr : p.t0;
-            const int tok = p.emb_tokens[(long)r * p.emb_tok_stride + t0];
-            const half_t *e = p.emb_E + (long)tok * K + kbeg + 8 * fq, *pe = p.emb_P + (long)t0 * K + kbeg + 8 * fq;
-            float *xo = const_cast<float *>(p.ln_x) + (long)r * K + kbeg + 8 * fq;
+        const float *xr = p.ln_x + (long)r * K + kbeg + 8 * fq;
 #pragma unroll
-            for (int s = 0; s < STEPS; s++) {
-                const half8 ev = *reinterpret_cast<const half8 *>(e + 32 * s), pv = *reinterpret_cast<const half8 *>(pe + 32 * s);
-                xv[cb][s][0] = (f32x4){(float)ev[0] + (float)pv[0], (float)ev[1] + (float)pv[1], (float)ev[2] + (float)pv[2], (float)ev[3] + (float)pv[3]};
-                xv[cb][s][1] = (f32x4){(float)ev[4] + (float)pv[4], (float)ev[5] + (float)pv[5], (float)ev[6] + (float)pv[6], (float)ev[7] + (float)pv[7]};
-                if (blockIdx.x == 0 && 16 * cb + fr < p.R) {
-                    *reinterpret_cast<f32x4 *>(xo + 32 * s) = xv[cb][s][0];
-                    *reinterpret_cast<f32x4 *>(xo + 32 * s + 4) = xv[cb][s][1];
-                }
-            }
-        } else {
-            const float *xr = p.ln_x + (long)r * K + kbeg + 8 * fq;
-#pragma unroll
-            for (int s = 0; s < STEPS; s++) {
-                xv[cb][s][0] = *reinterpret_cast<const f32x4 *>(xr + 32 * s);
-                xv[cb][s][1] = *reinterpret_cast<const f32x4 *>(xr + 32 * s + 4);
-            }
+        for (int s = 0; s < STEPS; s++) {
+            xv[cb][s][0] = *reinterpret_cast<const f32x4 *>(xr + 32 * s);
+            xv[cb][s][1] = *reinterpret_cast<const f32x4 *>(xr + 32 * s + 4);
         }
     }
     for (int c = tid; c < K / 4; c += 256) {

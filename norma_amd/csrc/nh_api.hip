@@ -684,22 +684,9 @@ static void ln_skinny(nh_ctx *ctx, const LnW &ln, const LinW &W, int R, int N, i
 // pos_ptr != nullptr: the position comes from device memory (the step is being captured into a hipGraph).
 static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr, bool final_ln = true) {
     const int d = ctx->c.d_model, B = ctx->cur_batch, H = ctx->c.decoder_attention_heads, C = ctx->c.max_target_positions;
-    // the input embedding is built inside the first layer's fused LN + QKV launch when that form is available
-    static const bool no_embed_fusion = getenv("NORMA_HIP_NO_EMBED_FUSION") != nullptr;  // A/B switch
-    const bool fold_embed = skinny_ln_supported(B, 3 * d, d) && !no_embed_fusion;
-    if (!fold_embed) launch_embed(ctx->ds.tokens, C, ctx->tok_emb, ctx->dec_pos, ctx->dx, B, 1, pos, pos_ptr, d, ctx->sd);
-    bool first = true;
+    launch_embed(ctx->ds.tokens, C, ctx->tok_emb, ctx->dec_pos, ctx->dx, B, 1, pos, pos_ptr, d, ctx->sd);
     for (auto &L : ctx->dec) {
-        if (first && fold_embed) {
-            SkinnyParams p{};
-            p.pos_ptr = pos_ptr; p.ln_x = ctx->dx; p.ln_w = L.ln1.w; p.ln_b = L.ln1.b;
-            p.emb_tokens = ctx->ds.tokens; p.emb_tok_stride = C; p.emb_E = ctx->tok_emb; p.emb_P = ctx->dec_pos;
-            p.ldx = d; p.W = L.qkv.w; p.Wt = L.qkv.wt; p.bias = L.qkv.b; p.R = B; p.N = 3 * d; p.K = d; p.epi = SK_QKV;
-            p.out[0] = ctx->dq; p.out[1] = L.sk; p.out[2] = L.sv; p.ldo = d; p.d = d; p.t0 = pos; p.Tn = 1; p.ctx = C;
-            launch_skinny(p, ctx->sk_slabs, ctx->sk_tickets, ctx->sd);
-        } else
         ln_skinny(ctx, L.ln1, L.qkv, B, 3 * d, d, SK_QKV, ctx->dq, L.sk, L.sv, d, pos, C, pos_ptr);
-        first = false;
         launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos_ptr, ctx->sd, 1);  // head-major cache
         skinny(ctx, ctx->datt, d, L.o, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
         ln_skinny(ctx, L.ln2, L.cq, B, d, d, SK_F16, ctx->dq, nullptr, nullptr, d, 0, C, nullptr);

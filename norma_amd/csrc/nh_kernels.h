@@ -62,9 +62,6 @@ struct SkinnyParams {
     // LN(ln_x[r][0..K)) * ln_w + ln_b (eps 1e-5, two-pass f32 statistics), rounded to fp16 like layernorm_kernel does
     const float *ln_x, *ln_w, *ln_b;
     float ln_rk;  // 1.0f / K, filled in by launch_skinny
-    // with ln_x (per-layer fused form only): the rows are tok_emb[tokens[r][pos]] + dec_pos[pos] instead of being read from
-    // ln_x, and workgroup 0 stores them to ln_x (the decoder input embedding folded into the first layer's LN + QKV launch)
-    const int32_t *emb_tokens; long emb_tok_stride; const half_t *emb_E, *emb_P;
 };
 // true when launch_skinny can take its activations through the fused LayerNorm for this shape
 bool skinny_ln_supported(int R, int N, int K);
