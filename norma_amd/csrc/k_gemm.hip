@@ -593,6 +593,11 @@ void launch_gemm(const GemmParams &p, hipStream_t st) {
         }
         return;
     }
+    launch_gemm_128(p, st);
+}
+
+// the 128 x 128 kernel on any supported shape (N % 128 == 0, K % 64 == 0); also the reference of tools/gemm_check
+void launch_gemm_128(const GemmParams &p, hipStream_t st) {
     int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
     hipLaunchKernelGGL(gemm_f16_kernel, dim3(ntn * ntm), dim3(256), 0, st, p);
 }

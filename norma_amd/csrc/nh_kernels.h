@@ -39,6 +39,7 @@ struct GemmParams {
     const float *pos;                           // conv2: positional embedding [S][N]
 };
 void launch_gemm(const GemmParams &p, hipStream_t st);
+void launch_gemm_128(const GemmParams &p, hipStream_t st);  // always the 128 x 128 kernel
 
 // ---- skinny GEMM for the decoder: y[R][N] = x[R][K] . W[N][K]^T, R <= 64 rows -------------------
 enum SkinnyEpi {
