@@ -589,6 +589,9 @@ void launch_skinny(const SkinnyParams &p_in, float *slabs, unsigned *tickets, hi
 // decoder attention, one query row per (b, h): 4 waves split the keys, inside a wave 8 key slots x
 // 8 lanes (16 B of the 64-wide head each); each slot runs its own online softmax, merged at the end.
 // ---------------------------------------------------------------------------------------------------
+#ifndef DA_U
+#define DA_U 4  // key groups (8 keys each) whose K and V rows are in flight together per wave: 2 x DA_U KiB (8: cross-attention 43 -> 46 us)
+#endif
 struct AttnPart { float m, l; float acc[8]; };
 
 __device__ __forceinline__ void merge_part(AttnPart &a, float mo, float lo, const float (&ao)[8]) {
@@ -628,10 +631,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict_
     AttnPart st; st.m = -INFINITY; st.l = 0.f;
 #pragma unroll
     for (int c = 0; c < 8; c++) st.acc[c] = 0.f;
-    for (int j0 = kbeg; j0 < kend; j0 += 32) {
-        half8 kk[4], vv[4];
+    for (int j0 = kbeg; j0 < kend; j0 += 8 * DA_U) {
+        half8 kk[DA_U], vv[DA_U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < DA_U; u++) {
             int j = j0 + 8 * u + slot; if (j >= kend) j = kend - 1;
             // streamed once per token: non-temporal, so the K/V stream (491 MB per step at b32) does not evict the
             // decoder weights from the Infinity Cache between tokens
@@ -639,7 +642,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict_
             vv[u] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(vb + j * rs));
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < DA_U; u++) {
             float s = 0.f;
 #pragma unroll
             for (int c = 0; c < 8; c++) s += qv[c] * (float)kk[u][c];
