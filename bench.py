@@ -40,7 +40,7 @@ def main():
                          "serialised by a host lock, decodes of other batches overlap them")
     ap.add_argument("--no-pipelined-extra", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-new-tokens", type=int, default=8)
+    ap.add_argument("--cpu-new-tokens", type=int, default=96)
     args = ap.parse_args()
 
     import torch
