@@ -173,7 +173,7 @@ typedef struct nh_timings {
     double gemm_flops;  /* algorithmic FLOPs of those launches */
 } nh_timings;
 int nh_get_timings(nh_ctx *ctx, nh_timings *out);
-/* 1: bracket every encoder GEMM launch with HIP events (adds sync points; bench roofline only). */
+/* 1: bracket every encoder GEMM launch with a pair of HIP event records on its stream (no synchronisation; bench roofline). */
 int nh_set_profile_gemm(nh_ctx *ctx, int enable);
 
 #ifdef __cplusplus
