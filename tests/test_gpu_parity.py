@@ -110,7 +110,9 @@ def _stage_parity(name, enc, dec, B, seed=0):
 # runs -- persistent 256 x 256 GEMM with every epilogue, head-major cross K/V, tile-major GEMV weights, 10-step fused
 # LayerNorm -- checked against the oracle, not only for self-consistency
 @pytest.mark.parametrize("name,enc,dec,B", [("test-d128", 0, 1, 2), ("test-d128", 2, 2, 3), ("test-d256-mel128", 2, 2, 2),
-                                            ("distil-large-v3", 1, 1, 2)])
+                                            ("distil-large-v3", 1, 1, 2),
+                                            # the remaining widths of the reference's model table (d = 512, 768, 1024), one layer each
+                                            ("base.en", 1, 1, 1), ("small.en", 1, 1, 2), ("medium.en", 1, 1, 1)])
 def test_encoder_and_decoder_layers_match_oracle(name, enc, dec, B):
     for r in _stage_parity(name, enc, dec, B):
         assert r["enc_err"] <= 2e-3, r
