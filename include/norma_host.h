@@ -22,7 +22,7 @@ extern "C" {
 #define NM_DEVICE_METAL 2
 #define NM_DEVICE_ROCM 3
 
-/* monolingual::ModelType (monolingual.rs:32-46), in declaration order without the quantized/multi variants */
+/* monolingual::ModelType (monolingual.rs:32-46): the fp16 checkpoints first, then the quantised ones, then multilingual::ModelType */
 #define NM_MODEL_TINY_EN 0
 #define NM_MODEL_BASE_EN 1
 #define NM_MODEL_SMALL_EN 2
@@ -34,6 +34,14 @@ extern "C" {
  * config-{ext}.json / tokenizer-{ext}.json / model-{ext}-q80.gguf, ext = "tiny-en" / "tiny"; weights are dequantised at load */
 #define NM_MODEL_QUANTIZED_TINY_EN 7
 #define NM_MODEL_QUANTIZED_TINY 8
+/* multilingual::ModelType (multilingual.rs:47-57): load with language = NULL / "" (detected) or a fixed "<|xx|>" (MultiAsMono) */
+#define NM_MODEL_TINY 9
+#define NM_MODEL_BASE 10
+#define NM_MODEL_SMALL 11
+#define NM_MODEL_MEDIUM 12
+#define NM_MODEL_LARGE 13
+#define NM_MODEL_LARGE_V2 14
+#define NM_MODEL_LARGE_V3 15
 
 typedef struct nm_definition nm_definition; /* whisper::monolingual::Definition */
 typedef struct nm_model nm_model;           /* whisper::Model */

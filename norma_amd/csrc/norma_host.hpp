@@ -94,13 +94,17 @@ struct Error {
 enum class VocabVersion { V1, V2, EnV1, EnV2 };  // whisper/mod.rs:57-62
 
 // monolingual.rs:32-46 (ids/revisions are download metadata, out of scope offline)
+// monolingual::ModelType (monolingual.rs:32-46) followed by multilingual::ModelType (multilingual.rs:47-57); one Definition
+// class serves both families here (language fixed = monolingual / MultiAsMono, language detected = multilingual)
 enum class ModelType { TinyEn, BaseEn, SmallEn, MediumEn, DistilMediumEn, DistilLargeEnV2, DistilLargeEnV3,
-                       QuantizedTinyEn, QuantizedTiny };  // the q8_0 GGUF checkpoints (monolingual.rs:32-46, multilingual.rs:37-49)
+                       QuantizedTinyEn, QuantizedTiny,   // the q8_0 GGUF checkpoints
+                       Tiny, Base, Small, Medium, Large, LargeV2, LargeV3 };
 inline VocabVersion vocab_version(ModelType m) {  // monolingual.rs:99-110, multilingual.rs:73-84
     switch (m) {
-        case ModelType::DistilMediumEn: case ModelType::DistilLargeEnV2: case ModelType::QuantizedTiny: return VocabVersion::V1;
-        case ModelType::DistilLargeEnV3: return VocabVersion::V2;
-        default: return VocabVersion::EnV1;
+        case ModelType::TinyEn: case ModelType::BaseEn: case ModelType::SmallEn: case ModelType::MediumEn:
+        case ModelType::QuantizedTinyEn: return VocabVersion::EnV1;
+        case ModelType::DistilLargeEnV3: case ModelType::LargeV3: return VocabVersion::V2;
+        default: return VocabVersion::V1;
     }
 }
 // multilingual.rs:87-92 / the monolingual twin: file-name infix of the quantised checkpoints, nullptr for the others

@@ -45,7 +45,7 @@ class SelectedDevice:
 
 
 class ModelType(enum.IntEnum):
-    """monolingual::ModelType (monolingual.rs:32-46)."""
+    """monolingual::ModelType (monolingual.rs:32-46) and multilingual::ModelType (multilingual.rs:47-57)."""
     TinyEn = 0
     BaseEn = 1
     SmallEn = 2
@@ -55,6 +55,14 @@ class ModelType(enum.IntEnum):
     DistilLargeEnV3 = 6
     QuantizedTinyEn = 7     # q8_0 GGUF checkpoint (monolingual.rs), files *-tiny-en*
     QuantizedTiny = 8       # q8_0 GGUF checkpoint (multilingual.rs:49), files *-tiny*
+    # multilingual::ModelType (multilingual.rs:47-57): language=None detects the language, a fixed "<|xx|>" is MultiAsMono
+    Tiny = 9
+    Base = 10
+    Small = 11
+    Medium = 12
+    Large = 13
+    LargeV2 = 14
+    LargeV3 = 15
 
 
 QUANTIZED_EXT = {ModelType.QuantizedTinyEn: "tiny-en", ModelType.QuantizedTiny: "tiny"}

@@ -56,7 +56,7 @@ def test_host_layer_detects_once_per_transcription_and_clears_on_final_chunk():
     # position 0 decides the language; the script starts at position 2 (prompt_len - 1) as before
     pos[0] = (np.float32(1.2 / 0.02 / max(1.0, 14.0 / (cfg.d_model * 0.02))) * emb[want]).astype(np.float32)
     over["model.decoder.embed_positions.weight"] = pos.astype(np.float16).astype(np.float32)
-    d = host.Definition(host.ModelType.DistilLargeEnV3, host.SelectedDevice.Rocm(0))
+    d = host.Definition(host.ModelType.LargeV3, host.SelectedDevice.Rocm(0))   # multilingual::ModelType, V2 vocabulary
     model = d.blocking_try_to_model(cfg, tk, -1, tk.transcribe,
                                     ((n, a.astype(np.float16)) for n, a in synth.synth_weights(cfg, 1, over)))
     model.enable_language_detection(_lang_tokens(tk))
