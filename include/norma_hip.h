@@ -176,6 +176,12 @@ int nh_get_timings(nh_ctx *ctx, nh_timings *out);
 /* 1: bracket every encoder GEMM launch with a pair of HIP event records on its stream (no synchronisation; bench roofline). */
 int nh_set_profile_gemm(nh_ctx *ctx, int enable);
 
+/* A/B switches for the bit-exactness screens in tests/ (the defaults are the product configuration; nothing here
+ * changes results, only how the decode step is launched). */
+#define NH_OPT_DECODE_GRAPHS 0          /* 1 (default): replay the captured decode step; 0: launch every kernel eagerly */
+#define NH_OPT_FUSE_DECODE_LAYERNORM 1  /* 1 (default): LayerNorm inside the consuming GEMV; 0: stand-alone LayerNorm kernel */
+int nh_set_option(nh_ctx *ctx, int option, int value);
+
 #ifdef __cplusplus
 }
 #endif

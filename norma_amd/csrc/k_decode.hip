@@ -13,6 +13,8 @@
 //                        a 207 KB D2H + a fresh [V] mask H2D + three sync scalar reads per token.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "nh_kernels.h"
 
 __device__ __forceinline__ float gelu_tanh_d(float v) { return gelu_tanh_fast(v); }
@@ -507,12 +509,9 @@ static bool ln_steps_ok(int K) {
     return K % 128 == 0 && (s == 1 || s == 2 || s == 3 || s == 4 || s == 6 || s == 8 || s == 10);
 }
 static bool logits_lds_ok(int R, int N, int K) {
-    static const bool nt_env = getenv("NORMA_SK_LOGITS_NT") != nullptr;
-    return (N + 15) / 16 >= 2048 && R <= 32 && (size_t)(K >> 5) * 16 * ((R + 15) / 16) * 64 <= 96 * 1024 && !nt_env;
+    return (N + 15) / 16 >= 2048 && R <= 32 && (size_t)(K >> 5) * 16 * ((R + 15) / 16) * 64 <= 96 * 1024;
 }
 bool skinny_ln_supported(int R, int N, int K) {
-    static const bool off = getenv("NORMA_HIP_NO_LN_FUSION") != nullptr;  // A/B switch
-    if (off) return false;
     if (R > 32) return false;
     if ((N + 15) / 16 >= 2048) return logits_lds_ok(R, N, K) && K <= 128 * LN_MAX_STEPS && K % 128 == 0;
     return ln_steps_ok(K);
@@ -540,22 +539,19 @@ static void launch_skinny_ncb(const SkinnyParams &p, float *slabs, unsigned *tic
         return;
     }
     if (tiles >= 2048) {  // the tied-embedding logits: plenty of tiles, stream full rows
-        static const int nt_env = getenv("NORMA_SK_LOGITS_NT") ? atoi(getenv("NORMA_SK_LOGITS_NT")) : 0;
         const size_t lds = (size_t)(p.K >> 5) * 16 * NCB * 64;
-        if (nt_env == 0 && NCB <= 2 && lds <= 96 * 1024) {
-            static bool attr_set[5] = {false, false, false, false, false};
-            if (!attr_set[NCB]) {
+        if (NCB <= 2 && lds <= 96 * 1024) {
+            // hipFuncSetAttribute acts on the CURRENT device: remember it per device (contexts on several GPUs of one
+            // process, each driven by its own host thread)
+            static std::atomic<bool> attr_set[NH_MAX_DEVICES];
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (dev < 0 || dev >= NH_MAX_DEVICES || !attr_set[dev].load(std::memory_order_acquire)) {
                 hipFuncSetAttribute(reinterpret_cast<const void *>(&skinny_lds_kernel<NCB>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-                attr_set[NCB] = true;
+                if (dev >= 0 && dev < NH_MAX_DEVICES) attr_set[dev].store(true, std::memory_order_release);
             }
-            static const int nblk = getenv("NORMA_SK_LOGITS_BLOCKS") ? atoi(getenv("NORMA_SK_LOGITS_BLOCKS")) : 256;
-            hipLaunchKernelGGL((skinny_lds_kernel<NCB>), dim3(nblk), dim3(512), lds, st, p);
-        } else if (nt_env == 1) {
-            hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 1, 1>), dim3((tiles + 1) / 2), dim3(128), 0, st, p, slabs, tickets);
-        } else if (nt_env == 4) {
-            int waves = (tiles + 3) / 4;
-            hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 1, 4>), dim3((waves + 1) / 2), dim3(128), 0, st, p, slabs, tickets);
+            hipLaunchKernelGGL((skinny_lds_kernel<NCB>), dim3(256), dim3(512), lds, st, p);
         } else {
             int waves = (tiles + 1) / 2;
             hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 1, 2>), dim3((waves + 1) / 2), dim3(128), 0, st, p, slabs, tickets);
@@ -1031,9 +1027,6 @@ __global__ __launch_bounds__(256) void logit_step_kernel(const float *__restrict
         better(av, ai, __shfl_xor(av, o), __shfl_xor(ai, o));
         better(bv, bi, __shfl_xor(bv, o), __shfl_xor(bi, o));
     }
-#if defined(NH_LOGIT_DBG) && NH_LOGIT_DBG == 1
-    if (m == 12345.f) partials[0] = se + ts + av + bv + ai + bi; return;
-#endif
     if (lane == 0) { sh_f[w][0] = m; sh_f[w][1] = se; sh_f[w][2] = ts; sh_f[w][3] = tsinf; sh_f[w][4] = av; sh_f[w][5] = bv; sh_i[w][0] = ai; sh_i[w][1] = bi; }
     __syncthreads();
     if (tid == 0) {
@@ -1059,9 +1052,6 @@ __global__ __launch_bounds__(256) void logit_step_kernel(const float *__restrict
         sh_last = (t == LSPLIT - 1);
     }
     __syncthreads();
-#if defined(NH_LOGIT_DBG) && NH_LOGIT_DBG == 2
-    return;
-#endif
     if (!sh_last || w != 0) return;
     // ---- last workgroup of this sequence: combine and do the bookkeeping of model.rs:331-370 ----
     // one L2 round trip: lane 8 q + f fetches field f of partial q, thread 0 then walks them by shuffle

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
 
 void launch_layernorm(const float *x, const float *w, const float *b, half_t *y, float *y32, int M, int d,
                       hipStream_t st) {
-    static const int max_blocks = getenv("NORMA_LN_BLOCKS") ? atoi(getenv("NORMA_LN_BLOCKS")) : 2048;
+    const int max_blocks = 2048;  // grid-stride rows: the affine parameters are loaded once per workgroup
     int blocks = (M + 3) / 4;
     if (blocks > max_blocks) blocks = max_blocks;
     hipLaunchKernelGGL(layernorm_kernel, dim3(blocks), dim3(256), 0, st, x, w, b, y, y32, M, d);

@@ -18,6 +18,8 @@
 // stores.  The V^T segment uses the other orientation (4 consecutive rows of one column).
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "nh_kernels.h"
 
 #define BM 128
@@ -238,9 +240,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
 // finished one: block launch, first-fetch latency and the store drain (14 of 47 us per K = 1280 tile before) hide
 // under each other.  The epilogue therefore stays out of the ring: fp16 outputs go through a 2176-byte per-wave
 // image (16 rows x 64 columns, 136-byte pitch) behind it, so that every global store writes whole 128-byte rows.
-//
-// G2_ABL (tools/gbench only) ablates parts of the loop: 1 no LDS-DMA, 2 no fragment reads, 4 no barriers, 8 no
-// vmcnt waits, 16 every K-tile re-reads K-tile 0 (cache-hot).  Results are meaningless with any bit set.
 // ---------------------------------------------------------------------------------------------------
 #define G2_BM 256
 #define G2_BN 256
@@ -252,9 +251,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
 #define PP_RING (2 * PP_BUF)
 #define PP_EPI_PITCH 136  // bytes per image row (64 fp16 + 8 pad)
 #define PP_EPI_WAVE (16 * PP_EPI_PITCH)
-#ifndef G2_ABL
-#define G2_ABL 0
-#endif
 
 struct PPSource { unsigned ag[2][2], wg[2][2]; };  // [h][i]: 32-bit element offsets of this lane's eight source rows
 
@@ -280,7 +276,7 @@ __device__ __forceinline__ void pp_stage(const GemmParams &p, char *wbase, const
     const int h = (which >> 1) & 1;
     const bool isB = which == 1 || which == 2;
     char *dst = wbase + (t & 1) * PP_BUF + (isB ? 2 * PP_HT : 0) + h * PP_HT;
-    const unsigned ko = (G2_ABL & 16) ? 0u : (unsigned)t * 64u;
+    const unsigned ko = (unsigned)t * 64u;
     if (isB) {
         __builtin_amdgcn_global_load_lds((gbl_void *)(p.W + (size_t)(sg.wg[h][0] + ko)), (lds_void *)dst, 16, 0, 0);
         __builtin_amdgcn_global_load_lds((gbl_void *)(p.W + (size_t)(sg.wg[h][1] + ko)), (lds_void *)(dst + 8192), 16, 0, 0);
@@ -317,8 +313,7 @@ __device__ __forceinline__ void pp_main(const GemmParams &p, char *smem, char *w
 #define PP_PHASE(Q, BUF, WAIT, DO_ISSUE, ST)                                                                             \
     {                                                                                                                    \
         constexpr int tb_ = (BUF) * PP_BUF;                                                                              \
-        if ((G2_ABL & 2) && t > 0) {                                                                                     \
-        } else if ((Q) == 0) {                                                                                           \
+        if ((Q) == 0) {                                                                                                  \
             _Pragma("unroll") for (int j = 0; j < 2; j++) _Pragma("unroll") for (int ks = 0; ks < 2; ks++)             \
                 fb[j][ks] = *reinterpret_cast<const half8 *>(pb[ks] + (tb_ + 2 * PP_HT + 2048 * j));                    \
             __builtin_amdgcn_sched_barrier(0);                                                                           \
@@ -332,13 +327,12 @@ __device__ __forceinline__ void pp_main(const GemmParams &p, char *smem, char *w
                 fa[i][ks] = *reinterpret_cast<const half8 *>(pa[ks] + (tb_ + PP_HT + 2048 * i));                       \
         }                                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
-        if ((DO_ISSUE) && !(G2_ABL & 1)) pp_stage(p, wbase, sg, (ST), (Q) == 2 ? 0 : (Q) == 3 ? 1 : (Q) == 0 ? 2 : 3);  \
-        if (G2_ABL & 8) {                                                                                                \
-        } else if ((WAIT) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                         \
+        if (DO_ISSUE) pp_stage(p, wbase, sg, (ST), (Q) == 2 ? 0 : (Q) == 3 ? 1 : (Q) == 0 ? 2 : 3);                     \
+        if ((WAIT) == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                \
         else if ((WAIT) == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                           \
         else if ((WAIT) == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                           \
         else if ((WAIT) == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
-        if (!(G2_ABL & 4)) __builtin_amdgcn_s_barrier();                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                                    \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                               \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
         __builtin_amdgcn_s_setprio(1);                                                                                   \
@@ -352,7 +346,7 @@ __device__ __forceinline__ void pp_main(const GemmParams &p, char *smem, char *w
         }                                                                                                                \
         __builtin_amdgcn_s_setprio(0);                                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                                               \
-        if (!(G2_ABL & 4)) __builtin_amdgcn_s_barrier();                                                                 \
+        __builtin_amdgcn_s_barrier();                                                                                    \
     }
 
     // everything issued so far (prologue DMAs, the previous tile's stores, the residual tile) has landed
@@ -409,13 +403,6 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmParams p) {
     char *const img = smem + PP_RING + w * PP_EPI_WAVE;
 
     int vb = blockIdx.x, tm, tn;
-#if G2_ABL & 64
-    {   // spread the workgroups of an XCD over one tile period (~1.4 us per K-tile + ~8 us): s_sleep(8) ~ 0.21 us
-        const int spread_us = (p.K >> 6) * 14 / 10 + 8;
-        const int iters = (int)(blockIdx.x >> 3) * spread_us * 5 / 32;
-        for (int z = 0; z < iters; z++) __builtin_amdgcn_s_sleep(8);
-    }
-#endif
     pp_tile(vb, ntn, ntm, tm, tn);
     PPSource sg = pp_source(p, tm * G2_BM, tn * G2_BN);
     pp_prologue(p, wbase, sg);
@@ -458,12 +445,7 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmParams p) {
         }
 
         // ---- epilogue of tile (m0, n0) ----
-        if (G2_ABL & 128) {  // no epilogue; the accumulators stay live
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) asm volatile("" ::"v"(acc[i][j]));
-        } else if (vt) {
+        if (vt) {
             // lane holds rows m = mb + 4 fq + r of column n = nb + fr: per 16-column block j and 64-row half, a
             // [16 n][64 m] image (V^T); read back as 128-byte runs of 64 consecutive m
             half_t *dst = reinterpret_cast<half_t *>(seg == 0 ? p.out[0] : seg == 1 ? p.out[1] : p.out[2]);
@@ -529,7 +511,7 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmParams p) {
                     const int m = m0 + wm * 128 + 16 * i + mr;
                     const half4 lo = *reinterpret_cast<const half4 *>(img + mr * PP_EPI_PITCH + (lane & 7) * 16);
                     const half4 hi = *reinterpret_cast<const half4 *>(img + mr * PP_EPI_PITCH + (lane & 7) * 16 + 8);
-                    if (m < p.M && (!(G2_ABL & 32) || lo[0] == (half_t)123.456f)) {
+                    if (m < p.M) {
                         half8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         // head-major: the wave's 64 columns are one head (seg_n and the tile base are multiples of 64)
                         half_t *dst = p.head_major ? ob + (((long)(m / p.S) * p.H + (ncol >> 6)) * p.S + m % p.S) * NH_DH + (lane & 7) * 8
@@ -568,21 +550,22 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmParams p) {
     }
 }
 
-static const bool g_gemm_small_only = getenv("NORMA_HIP_GEMM128") != nullptr;  // A/B switch: force the 128^2 kernel
-
+// CU count of the CURRENT device, cached per device (one process may drive several GPUs from several threads)
 static int device_cu_count() {
-    static int n = 0;
+    static std::atomic<int> cus[NH_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NH_MAX_DEVICES) return 256;
+    int n = cus[dev].load(std::memory_order_relaxed);
     if (!n) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
-        if (n <= 0) n = 256;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev].store(n, std::memory_order_relaxed);
     }
     return n;
 }
 
 void launch_gemm(const GemmParams &p, hipStream_t st) {
     const bool seg_ok = (p.epi != EPI_F16 && p.epi != EPI_GELU_F16) || (p.seg_n % G2_BN == 0);
-    if (!g_gemm_small_only && p.N % G2_BN == 0 && p.K % 128 == 0 && seg_ok && p.M >= G2_BM) {
+    if (p.N % G2_BN == 0 && p.K % 128 == 0 && seg_ok && p.M >= G2_BM) {
         const int nwg = (p.N / G2_BN) * ((p.M + G2_BM - 1) / G2_BM);
         int cus = device_cu_count();
         cus -= cus % 8;  // the tile order assumes workgroups b and b + gridDim.x sit on the same XCD

@@ -24,7 +24,8 @@
         }                                                                                     \
     } while (0)
 
-static std::string g_create_error;
+// message of the last failed nh_create on THIS thread (contexts are created from one thread per GPU)
+static thread_local std::string g_create_error;
 
 struct LinW { half_t *w = nullptr; float *b = nullptr; half_t *wt = nullptr; /* tile-major repack (decoder GEMVs) */ };
 struct LnW { float *w = nullptr, *b = nullptr; };
@@ -77,6 +78,8 @@ struct nh_ctx {
     hipGraphExec_t step_graph = nullptr;   // one decode step
     hipGraphExec_t multi_graph = nullptr;  // NH_GRAPH_STEPS consecutive steps (one launch gap instead of NH_GRAPH_STEPS)
     int graph_key[5] = {-1, -1, -1, -1, -1};
+    int token_gen = 0;  // bumped by nh_set_tokens; part of the graph key
+    bool opt_graphs = true, opt_fuse_ln = true;  // nh_set_option
     std::vector<int32_t> seq_lang;  // per-sequence language tokens (LanguageState::Detect), empty = tk.lang for all
     int32_t *d_lang_tokens = nullptr, *d_lang_out = nullptr;
     float *d_lang_probs = nullptr;
@@ -98,6 +101,14 @@ struct nh_ctx {
 
     int fail(int code, const std::string &msg) { err = msg; return code; }
 };
+
+// the captured decode-step graphs bake in everything the step kernels take by value (batch, encoder length, the rule
+// token ids, the max_new_tokens knob): whoever changes one of those drops the graphs, the next greedy decode re-captures
+static void drop_graphs(nh_ctx *ctx) {
+    if (ctx->step_graph) { hipGraphExecDestroy(ctx->step_graph); ctx->step_graph = nullptr; }
+    if (ctx->multi_graph) { hipGraphExecDestroy(ctx->multi_graph); ctx->multi_graph = nullptr; }
+    for (int &k : ctx->graph_key) k = -1;
+}
 
 template <typename T>
 static T *dalloc(nh_ctx *ctx, size_t n, bool zero = true) {
@@ -156,8 +167,7 @@ extern "C" void nh_destroy(nh_ctx *ctx) {
     if (ctx->st) hipStreamSynchronize(ctx->st);
     if (ctx->sd) hipStreamSynchronize(ctx->sd);
     for (void *p : ctx->allocs) hipFree(p);
-    if (ctx->step_graph) hipGraphExecDestroy(ctx->step_graph);
-    if (ctx->multi_graph) hipGraphExecDestroy(ctx->multi_graph);
+    drop_graphs(ctx);
     if (ctx->h_done) hipHostFree(ctx->h_done);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     for (auto &e : ctx->gemm_ev) hipEventDestroy(e);
@@ -481,6 +491,8 @@ extern "C" int nh_set_tokens(nh_ctx *ctx, const nh_tokens *tk, const int32_t *su
     HIPCHK(hipMemcpy(ctx->suppress, sup.data(), V, hipMemcpyHostToDevice));
     ctx->tk = RuleTokens{tk->sot, tk->eot, tk->lang, tk->task, tk->no_speech, tk->no_timestamps, tk->zero_sec, tk->one_sec};
     ctx->have_tokens = true;
+    ctx->token_gen++;  // the captured step graphs carry the old ids by value (logit_step_kernel): re-capture
+    drop_graphs(ctx);
     return NH_OK;
 }
 
@@ -671,7 +683,7 @@ static void dec_layernorm(nh_ctx *ctx, const LnW &ln, half_t *y, float *y32, int
 // LayerNorm launch is pure latency at B rows), otherwise LayerNorm into dxn first
 static void ln_skinny(nh_ctx *ctx, const LnW &ln, const LinW &W, int R, int N, int K, int epi, void *o0, void *o1, void *o2,
                       long ldo, int t0, int ctxlen, const int32_t *pos_ptr) {
-    if (skinny_ln_supported(R, N, K)) {
+    if (ctx->opt_fuse_ln && skinny_ln_supported(R, N, K)) {
         skinny(ctx, nullptr, K, W, R, N, K, epi, o0, o1, o2, ldo, t0, ctxlen, pos_ptr, ctx->dx, ln.w, ln.b);
     } else {
         dec_layernorm(ctx, ln, ctx->dxn, nullptr, R, K);
@@ -702,7 +714,7 @@ static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr,
 static void logits_from_dx(nh_ctx *ctx, int R) {
     LinW E; E.w = ctx->tok_emb; E.wt = ctx->tok_emb_t; E.b = nullptr;  // tied embedding, no bias (final_linear)
     const int d = ctx->c.d_model, V = ctx->c.vocab_size;
-    if (skinny_ln_supported(R, V, d)) {
+    if (ctx->opt_fuse_ln && skinny_ln_supported(R, V, d)) {
         skinny(ctx, nullptr, d, E, R, V, d, SK_F32, ctx->logits, nullptr, nullptr, ctx->VP, 0, 0, nullptr, ctx->dx, ctx->dec_ln.w, ctx->dec_ln.b);
     } else {
         dec_layernorm(ctx, ctx->dec_ln, ctx->dxn, nullptr, R, d);
@@ -762,24 +774,32 @@ static int decode_impl(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *resul
     // Generation phase: one token per step from pos = P-1 on.  The length cap (model.rs:367) forces eot once
     // pos + 2 >= cap, so pos never exceeds cap - 2.  The ~20-launch step is captured (once, and 8 steps back to back) into hipGraphs that
     // reads the position from device memory (the eager loop is host-launch-bound at ~5 us per tiny kernel).
-    static const bool no_graph_env = getenv("NORMA_HIP_NO_GRAPH") != nullptr;
-    const bool no_graph = no_graph_env || inv_t > 0.f;
-    const int key[5] = {B, ctx->S, max_new_tokens, P, 1};
+    const bool no_graph = !ctx->opt_graphs || inv_t > 0.f;
+    const int key[5] = {B, ctx->S, max_new_tokens, P, ctx->token_gen};
     if (!no_graph && memcmp(key, ctx->graph_key, sizeof(key)) != 0) {
-        if (ctx->step_graph) { hipGraphExecDestroy(ctx->step_graph); ctx->step_graph = nullptr; }
-        if (ctx->multi_graph) { hipGraphExecDestroy(ctx->multi_graph); ctx->multi_graph = nullptr; }
+        drop_graphs(ctx);
         for (int which = 0; which < 2; which++) {
             hipGraph_t g = nullptr;
-            HIPCHK(hipStreamBeginCapture(ctx->sd, hipStreamCaptureModeThreadLocal));
+            hipError_t ge = hipStreamBeginCapture(ctx->sd, hipStreamCaptureModeThreadLocal);
+            if (ge != hipSuccess) return ctx->fail(NH_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(ge));
             for (int i = 0; i < (which ? NH_GRAPH_STEPS : 1); i++) {  // every step reads and advances the device-side position
                 decoder_step(ctx, 0, ctx->d_pos, false);
                 logits_from_dx(ctx, B);
                 launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, ctx->d_pos, ctx->sd);
             }
-            HIPCHK(hipStreamEndCapture(ctx->sd, &g));
-            hipError_t ge = hipGraphInstantiate(which ? &ctx->multi_graph : &ctx->step_graph, g, nullptr, nullptr, 0);
-            hipGraphDestroy(g);
-            if (ge != hipSuccess) return ctx->fail(NH_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ge));
+            // the stream must leave capture mode whatever happened in between; a failed capture leaves no graph behind
+            ge = hipStreamEndCapture(ctx->sd, &g);
+            if (ge == hipSuccess && !g) ge = hipErrorStreamCaptureInvalidated;
+            if (ge == hipSuccess) {
+                ge = hipGraphInstantiate(which ? &ctx->multi_graph : &ctx->step_graph, g, nullptr, nullptr, 0);
+                if (ge != hipSuccess) (which ? ctx->multi_graph : ctx->step_graph) = nullptr;
+            }
+            if (g) hipGraphDestroy(g);
+            if (ge != hipSuccess) {
+                (void)hipGetLastError();
+                drop_graphs(ctx);
+                return ctx->fail(NH_ERR_HIP, std::string("decode-step graph capture: ") + hipGetErrorString(ge));
+            }
         }
         memcpy(ctx->graph_key, key, sizeof(key));
     }
@@ -1002,6 +1022,14 @@ extern "C" int nh_apply_rules(nh_ctx *ctx, const float *probs, const int32_t *to
 extern "C" int nh_set_profile_gemm(nh_ctx *ctx, int enable) {
     if (!ctx) return NH_ERR_INVALID;
     ctx->profile_gemm = enable != 0;
+    return NH_OK;
+}
+
+extern "C" int nh_set_option(nh_ctx *ctx, int option, int value) {
+    if (!ctx) return NH_ERR_INVALID;
+    if (option == NH_OPT_DECODE_GRAPHS) ctx->opt_graphs = value != 0;
+    else if (option == NH_OPT_FUSE_DECODE_LAYERNORM) { ctx->opt_fuse_ln = value != 0; drop_graphs(ctx); }
+    else return ctx->fail(NH_ERR_INVALID, "nh_set_option: unknown option " + std::to_string(option));
     return NH_OK;
 }
 

@@ -15,6 +15,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define NH_MELP 128   // mel channels padded to 128 in the fp16 conv1 input (K = 3*128)
 #define NH_SP 1536    // encoder sequence padded to a multiple of 64 for the V^T image
 #define NH_DH 64      // head dim of every Whisper size
+#define NH_MAX_DEVICES 64  // per-device caches of the launchers (one process may hold contexts on several GPUs)
 
 // ---- big MFMA GEMM: C[M][N] = A[M][K] . W[N][K]^T (+bias), fp16 in, fp32 accumulate ------------
 enum GemmEpi {

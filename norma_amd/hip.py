@@ -20,6 +20,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "norma_hip.h")
 N_SAMPLES = 480000
 N_FRAMES = 3000
 NH_DTYPE_F32, NH_DTYPE_F16 = 0, 1
+NH_OPT_DECODE_GRAPHS, NH_OPT_FUSE_DECODE_LAYERNORM = 0, 1
 
 
 class HipError(RuntimeError):
@@ -101,6 +102,7 @@ def load_library() -> C.CDLL:
     L.nh_apply_rules.argtypes = [vp, fp, ip, C.c_int, C.c_int, fp, ip]
     L.nh_get_timings.argtypes = [vp, C.POINTER(NhTimings)]
     L.nh_set_profile_gemm.argtypes = [vp, C.c_int]
+    L.nh_set_option.argtypes = [vp, C.c_int, C.c_int]
     _lib = L
     return L
 
@@ -189,6 +191,14 @@ class HipWhisper:
         for b, c in enumerate(clips):
             buf[b, :len(c)] = c
         self._chk(self.L.nh_logmel(self._h, _fp(buf), _ip(ns), stride, B))
+        self.batch = B
+
+    def logmel_array(self, pcm: np.ndarray, n_samples: Optional[Sequence[int]] = None):
+        """pcm: contiguous f32 [batch][stride] in HOST memory, handed to nh_logmel as is (no staging copy here)."""
+        assert pcm.dtype == np.float32 and pcm.ndim == 2 and pcm.flags.c_contiguous
+        B, stride = pcm.shape
+        ns = np.full(B, stride, dtype=np.int32) if n_samples is None else np.asarray(n_samples, dtype=np.int32)
+        self._chk(self.L.nh_logmel(self._h, _fp(pcm), _ip(ns), stride, B))
         self.batch = B
 
     def logmel_device(self, pcm_dev_ptr: int, n_samples: Sequence[int], stride: int):
@@ -310,6 +320,10 @@ class HipWhisper:
     # -- instrumentation ---------------------------------------------------------------------------
     def set_profile_gemm(self, enable: bool):
         self._chk(self.L.nh_set_profile_gemm(self._h, int(enable)))
+
+    def set_option(self, option: int, value: int):
+        """A/B switches of include/norma_hip.h (NH_OPT_*): how the decode step is launched, never what it computes."""
+        self._chk(self.L.nh_set_option(self._h, int(option), int(value)))
 
     def timings(self) -> dict:
         t = NhTimings()

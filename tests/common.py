@@ -45,6 +45,27 @@ def build_hip(cfg, tk, seed=0, overrides=None, max_batch=1, device=0, lang=None)
     return hm
 
 
+def build_together(cfg, tk, seed=0, overrides=None, batches=(1,), device=0, lang=None, with_oracle=True):
+    """One pass over the synthetic tensors feeding an oracle and several HIP contexts (large-v3 is 6.2 GB in f32: the
+    tensors are generated once).  Returns (oracle or None, [HipWhisper per entry of `batches`])."""
+    from norma_amd import hip
+    om = None
+    if with_oracle:
+        from oracle import oracle as O
+        om = O.OracleModel(cfg, tk, tk.en if lang is None else lang, tk.transcribe)
+    hms = [hip.HipWhisper(cfg, device=device, max_batch=b) for b in batches]
+    for n, a in synth.synth_weights(cfg, seed, overrides):
+        if om is not None:
+            om.set_tensor(n, a)
+        a16 = a.astype(np.float16)
+        for h in hms:
+            h.load_tensor(n, a16)
+    for h in hms:
+        h.set_mel_filters(assets_io.mel_filters(cfg.num_mel_bins))
+        h.set_tokens(tk, tk.en if lang is None else lang, tk.transcribe)
+    return om, hms
+
+
 def scripted_overrides(cfg, tk, script, pos_rms=1.2, seed=0, peak_logit=14.0):
     """Weights that steer the greedy decode along `script` with a wide margin at every step
     (see synth.script_positions): the tied embedding is scaled so that a hidden state aligned with a

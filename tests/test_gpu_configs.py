@@ -1,0 +1,149 @@
+"""GPU: BASELINE.json configs 4 and 5 at FULL size.
+
+config 5  Whisper large-v3 multilingual (32 + 32 layers, V2 vocabulary), batch 64, language detection + timestamp decoding:
+          Model::detect_language (src/models/whisper/model.rs:194-210), the [sot, lang, task] prompt (:285-289,
+          multilingual.rs:383-398) and the timestamp rules (:212-277) -- one clip against the oracle end to end, then the
+          b64 batch through size-independent properties (determinism, clip alone == clip in the batch, bit for bit).
+config 4  distil-large-v3 long-form: a 10-minute clip = 20 chunks, sharded 3,3,3,3,2,2,2,2 (norma_amd.shard.partition);
+          every rank's slice is run on the one GPU of the box, packed/unpacked like the RCCL gather does, and the union
+          must equal the single 20-chunk pass; bench.py's own 2-rank launcher is run on top (gloo, both ranks on cuda:0).
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import common
+from norma_amd import assets_io, config, shard, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _lang_tokens(tk):
+    return [tk.en + i for i in range(99)]
+
+
+def _multilingual_overrides(cfg, tk, script, want_lang):
+    """scripted transcript from position 2 on (prompt [sot, lang, task]) + a language decided at position 0"""
+    over = common.scripted_overrides(cfg, tk, script)
+    emb = over["model.decoder.embed_tokens.weight"]
+    pos = over["model.decoder.embed_positions.weight"].copy()
+    pos[0] = (np.float32(1.2 / 0.02 / max(1.0, 14.0 / (cfg.d_model * 0.02))) * emb[want_lang]).astype(np.float32)
+    over["model.decoder.embed_positions.weight"] = pos.astype(np.float16).astype(np.float32)
+    return over
+
+
+def test_config5_large_v3_full_size_language_detection_and_timestamps():
+    from oracle import oracle as O
+    name = "large-v3"
+    cfg = config.preset(name)
+    tk = common.tokens_for(name)
+    assert (cfg.encoder_layers, cfg.decoder_layers, cfg.vocab_size, cfg.num_mel_bins) == (32, 32, 51866, 128)
+    script = common.transcript_script(tk, n_segments=4, words_per_segment=7, seed=11)   # <|t|> words <|t|> <|t|> words ... eot
+    want = tk.en + 23
+    over = _multilingual_overrides(cfg, tk, script, want)
+    om, (h1, h64) = common.build_together(cfg, tk, overrides=over, batches=(1, 64), lang=-1)
+    filt = assets_io.mel_filters(cfg.num_mel_bins)
+    langs = _lang_tokens(tk)
+    clips = [synth.synth_pcm(k) for k in range(64)]
+
+    # ---- one clip, every layer, against the oracle ----
+    h1.logmel([clips[9]]); h1.encode()
+    got_lang, got_probs = h1.detect_language(langs)
+    got = h1.decode_greedy()[0]
+    xa = om.encoder_forward(O.pcm_to_mel(clips[9], filt))
+    enc_err = float(np.abs(h1.encoder_output(0) - xa).max())
+    assert enc_err <= 4e-3, enc_err
+    ref_lang, ref_probs = om.detect_language(xa, langs)
+    assert got_lang[0] == ref_lang == want
+    assert np.abs(got_probs[0] - ref_probs).max() <= 2e-3 * ref_probs.max() + 1e-6
+    om.set_language(ref_lang)
+    ref = om.decode(xa)
+    assert got["tokens"] == ref["tokens"] == [tk.sot, want, tk.transcribe] + script
+    assert sum(t > tk.no_timestamps for t in got["tokens"]) >= 7          # the timestamp grammar was exercised
+    assert abs(got["avg_logprob"] - ref["avg_logprob"]) <= 5e-3
+    assert abs(got["no_speech_prob"] - ref["no_speech_prob"]) <= 0.02 * ref["no_speech_prob"] + 1e-9
+    om.close()
+
+    # ---- the b64 batch at full size: 15.7 GB of cross K/V, 4-column-block decoder kernels ----
+    h64.logmel(clips); h64.encode()
+    l64, _ = h64.detect_language(langs)
+    r64 = h64.decode_greedy()
+    assert l64 == [want] * 64
+    for r in r64:
+        assert r["tokens"] == [tk.sot, want, tk.transcribe] + script
+    h64.logmel(clips); h64.encode()
+    l64b, _ = h64.detect_language(langs)
+    again = h64.decode_greedy()
+    assert l64b == l64
+    for a, b in zip(r64, again):                                          # determinism
+        assert a["tokens"] == b["tokens"] and a["avg_logprob"] == b["avg_logprob"] and a["no_speech_prob"] == b["no_speech_prob"]
+    assert np.array_equal(h64.encoder_output(9), h1.encoder_output(0))    # clip 9 in the batch == clip 9 alone, bit for bit
+    assert r64[9]["tokens"] == got["tokens"] and r64[9]["avg_logprob"] == got["avg_logprob"]
+    assert r64[9]["no_speech_prob"] == got["no_speech_prob"]
+    assert len({r["avg_logprob"] for r in r64}) > 32                      # the clips do differ: the log-probs depend on the audio
+    h1.close(); h64.close()
+
+
+def test_config4_longform_20_chunks_sharded_over_8_ranks_equals_the_single_pass():
+    name = "distil-large-v3"
+    cfg = config.preset(name)
+    tk = common.tokens_for(name)
+    C = cfg.max_target_positions
+    script = common.transcript_script(tk, n_segments=5, words_per_segment=8, seed=4)
+    over = common.scripted_overrides(cfg, tk, script)
+    _, (hm,) = common.build_together(cfg, tk, overrides=over, batches=(20,), with_oracle=False)
+    # the 10-minute clip: 9 600 000 samples, chunk k = synth_pcm(k)
+    long_clip = np.concatenate([synth.synth_pcm(k) for k in range(20)])
+    assert long_clip.shape == (9_600_000,)
+    chunks = long_clip.reshape(20, synth.N_SAMPLES)
+    hm.logmel_array(chunks); hm.encode()
+    single = hm.decode_greedy()
+    assert len(single) == 20
+    parts = shard.partition(20, 8)
+    assert [c for _, c in parts] == [3, 3, 3, 3, 2, 2, 2, 2]
+    slots = max(c for _, c in parts)
+    union = []
+    for start, count in parts:                       # rank r's work, run on this box's one GPU
+        hm.logmel_array(np.ascontiguousarray(chunks[start:start + count])); hm.encode()
+        local = hm.decode_greedy()
+        wire = shard.pack_results(local, C, slots)   # what the all_gather carries
+        union.extend(shard.unpack_results(wire, C, count))
+    assert len(union) == 20
+    for k, (a, b) in enumerate(zip(single, union)):
+        assert a["tokens"] == b["tokens"], k
+        assert a["avg_logprob"] == b["avg_logprob"] and a["no_speech_prob"] == b["no_speech_prob"], k
+        assert a["tokens"] == [tk.sot, tk.en, tk.transcribe] + script
+    assert len({r["avg_logprob"] for r in single}) > 10
+    hm.close()
+
+
+def test_bench_launches_its_own_ranks_and_gathers_the_longform_job():
+    """`bench.py --gpus 2` with no external launcher: two child processes (both on cuda:0 of this one-GPU box, gloo for the
+    rendezvous and the gather), the 20-chunk job split 10 + 10, gathered on rank 0; the token ids must equal the
+    single-process run of the same job."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    args = ["--workload", "longform20", "--steps", "1", "--warmup", "0", "--max-new-tokens", "24", "--no-cpu-baseline",
+            "--print-tokens-hash"]
+    lines = []
+    for n in (1, 2):
+        e = dict(env)
+        if n > 1:
+            e.update(NORMA_BENCH_BACKEND="gloo", NORMA_BENCH_FORCE_DEVICE="0")
+        p = subprocess.run([sys.executable, os.path.join(common.ROOT, "bench.py"), "--gpus", str(n)] + args, cwd=common.ROOT,
+                           env=e, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        js = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        assert len(js) == 1
+        lines.append(json.loads(js[0]))
+    one, two = lines
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["scaling"] == "strong" and two["config"]["chunks"] == 20 and two["config"]["batch_per_gpu"] == 10
+    assert one["results"] == two["results"] == 20
+    assert one["tokens_hash"] == two["tokens_hash"]
+    assert two["value"] > 0 and two["roofline"]["time_weighted_frac"] > 0

@@ -351,30 +351,62 @@ def test_clip_shorter_than_one_hop_uses_the_1500_frame_path():
 
 
 @pytest.mark.gpu
-def test_fused_layernorm_decode_is_bit_identical_to_the_unfused_path():
+def test_fused_layernorm_decode_and_graph_replay_are_bit_identical_to_the_plain_path():
     """The decode step fuses every LayerNorm into the projection that consumes it (skinny_ln_kernel, the logits staging
-    pass).  NORMA_HIP_NO_LN_FUSION=1 runs the stand-alone sliced LayerNorm + plain GEMM instead; both must give the same
-    tokens and bit-identical log-probabilities (one summation tree, one rounding sequence: nh_kernels.h)."""
-    import subprocess, sys, json
-    prog = (
-        "import sys, json; sys.path.insert(0, 'tests'); sys.path.insert(0, '.');\n"
-        "import common; from norma_amd import config, synth\n"
-        "name = 'test-d256-mel128'; cfg = config.preset(name); tk = common.tokens_for(name)\n"
-        "script = common.transcript_script(tk, n_segments=3, words_per_segment=6, seed=21)\n"
-        "hm = common.build_hip(cfg, tk, seed=1, overrides=common.scripted_overrides(cfg, tk, script), max_batch=3)\n"
-        "hm.logmel([synth.synth_pcm(k, 480000) for k in (17, 4, 9)]); hm.encode(); r = hm.decode_greedy()\n"
-        "print(json.dumps([[x['tokens'], x['avg_logprob'].hex(), x['no_speech_prob'].hex()] for x in r]))\n")
+    pass) and is replayed from a hipGraph.  nh_set_option switches either off (stand-alone sliced LayerNorm + plain GEMV;
+    eager launches with the position passed by value); all four combinations must give the same tokens and bit-identical
+    log-probabilities (one summation tree, one rounding sequence: nh_kernels.h)."""
+    from norma_amd import hip
+    name = "test-d256-mel128"
+    cfg = config.preset(name)
+    tk = common.tokens_for(name)
+    script = common.transcript_script(tk, n_segments=3, words_per_segment=6, seed=21)
+    hm = common.build_hip(cfg, tk, seed=1, overrides=common.scripted_overrides(cfg, tk, script), max_batch=3)
+    hm.logmel([synth.synth_pcm(k, 480000) for k in (17, 4, 9)]); hm.encode()
     outs = []
-    for fuse in (True, False):
-        env = dict(os.environ)
-        env.pop("NORMA_HIP_NO_LN_FUSION", None)
-        if not fuse:
-            env["NORMA_HIP_NO_LN_FUSION"] = "1"
-        p = subprocess.run([sys.executable, "-c", prog], cwd=common.ROOT, env=env, capture_output=True, text=True, timeout=300)
-        assert p.returncode == 0, p.stderr[-2000:]
-        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
-    assert outs[0] == outs[1]
+    for graphs in (1, 0):
+        for fuse in (1, 0):
+            hm.set_option(hip.NH_OPT_DECODE_GRAPHS, graphs)
+            hm.set_option(hip.NH_OPT_FUSE_DECODE_LAYERNORM, fuse)
+            r = hm.decode_greedy()
+            outs.append([[x["tokens"], x["avg_logprob"].hex(), x["no_speech_prob"].hex()] for x in r])
+    assert outs[0] == outs[1] == outs[2] == outs[3]
     assert len(outs[0][0][0]) > 10
+    hm.close()
+
+
+@pytest.mark.gpu
+def test_set_tokens_after_a_decode_recaptures_the_step_graph():
+    """The captured decode step carries the rule token ids by value: a second nh_set_tokens must not replay the old ids
+    (ADVICE r01).  Decode, re-declare the special tokens with a different eot / timestamp origin, decode again: both
+    passes must match the oracle configured the same way."""
+    import dataclasses
+    O = _oracle()
+    name = "test-d128"
+    cfg = config.preset(name)
+    tk = common.tokens_for(name)
+    script = common.transcript_script(tk, n_segments=2, words_per_segment=4, seed=8)
+    over = common.scripted_overrides(cfg, tk, script)
+    hm = common.build_hip(cfg, tk, overrides=over, max_batch=1)
+    clip = synth.synth_pcm(3)
+    mel = O.pcm_to_mel(clip, assets_io.mel_filters(cfg.num_mel_bins))
+    hm.logmel([clip]); hm.encode()
+    first = hm.decode_greedy()[0]
+    om = common.build_oracle(cfg, tk, overrides=over)
+    xa = om.encoder_forward(mel)
+    assert first["tokens"] == om.decode(xa)["tokens"] == [tk.sot, tk.en, tk.transcribe] + script
+    om.close()
+    # new ids: the FIRST text token of the script becomes eot -> the transcript must now stop there
+    tk2 = dataclasses.replace(tk, eot=script[1])
+    hm.set_tokens(tk2, tk2.en, tk2.transcribe)
+    second = hm.decode_greedy()[0]
+    om2 = O.OracleModel(cfg, tk2, tk2.en, tk2.transcribe)
+    for n, a in synth.synth_weights(cfg, 0, over):
+        om2.set_tensor(n, a)
+    ref2 = om2.decode(om2.encoder_forward(mel))
+    assert second["tokens"] == ref2["tokens"]
+    assert second["tokens"] != first["tokens"] and second["tokens"][-1] == script[1]
+    hm.close(); om2.close()
 
 
 @pytest.mark.gpu
