@@ -26,12 +26,15 @@ def _lang_tokens(tk):
     return [tk.en + i for i in range(99)]
 
 
-def _multilingual_overrides(cfg, tk, script, want_lang):
-    """scripted transcript from position 2 on (prompt [sot, lang, task]) + a language decided at position 0"""
-    over = common.scripted_overrides(cfg, tk, script)
+def _multilingual_overrides(cfg, tk, script, want_lang, pos_rms=1.2):
+    """scripted transcript from position 2 on (prompt [sot, lang, task]) + a language decided at position 0.
+    pos_rms: how strongly the positional table steers; 32 random decoder layers dilute it (at 1.2 the oracle itself leaves
+    the script at the third token: summed timestamp mass 0.027 vs best text 0.024), 3.0 gives a trained-model-like peaked
+    distribution at that depth (oracle: min p(next) 0.83, avg_logprob -0.04)."""
+    over = common.scripted_overrides(cfg, tk, script, pos_rms=pos_rms)
     emb = over["model.decoder.embed_tokens.weight"]
     pos = over["model.decoder.embed_positions.weight"].copy()
-    pos[0] = (np.float32(1.2 / 0.02 / max(1.0, 14.0 / (cfg.d_model * 0.02))) * emb[want_lang]).astype(np.float32)
+    pos[0] = (np.float32(pos_rms / 0.02 / max(1.0, 14.0 / (cfg.d_model * 0.02))) * emb[want_lang]).astype(np.float32)
     over["model.decoder.embed_positions.weight"] = pos.astype(np.float16).astype(np.float32)
     return over
 
@@ -44,7 +47,7 @@ def test_config5_large_v3_full_size_language_detection_and_timestamps():
     assert (cfg.encoder_layers, cfg.decoder_layers, cfg.vocab_size, cfg.num_mel_bins) == (32, 32, 51866, 128)
     script = common.transcript_script(tk, n_segments=4, words_per_segment=7, seed=11)   # <|t|> words <|t|> <|t|> words ... eot
     want = tk.en + 23
-    over = _multilingual_overrides(cfg, tk, script, want)
+    over = _multilingual_overrides(cfg, tk, script, want, pos_rms=3.0)
     om, (h1, h64) = common.build_together(cfg, tk, overrides=over, batches=(1, 64), lang=-1)
     filt = assets_io.mel_filters(cfg.num_mel_bins)
     langs = _lang_tokens(tk)
