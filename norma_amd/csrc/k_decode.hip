@@ -23,8 +23,9 @@ __device__ __forceinline__ float gelu_tanh_d(float v) { return gelu_tanh_fast(v)
 // skinny GEMM: y[R][N] = x[R][K] . W[N][K]^T, R <= 64.  Weights are the MFMA A operand (16 rows per
 // tile; each lane streams 16 B of one weight row per k-step, 4 lanes cover a 64 B run), activations
 // (L2-resident) the B operand.  Two shapes of the same kernel:
-//   KSPLIT = 4 | 8 : one 16-row tile per workgroup, its KSPLIT waves split K, fp32 partials meet in
-//                    LDS (small N: many waves in flight instead of few long ones);
+//   KSPLIT = 2 .. 16 : one 16-row tile per workgroup, its KSPLIT waves split K, fp32 partials meet in
+//                    LDS (small N: many waves in flight instead of few long ones; the long-K fc2 layer
+//                    takes 16 waves so that every wave still has ONE group of <= 10 k-steps in flight);
 //   KSPLIT = 1     : every wave owns NT 16-row tiles over the full K, no LDS (the 51866-row logits).
 // Up to 8 k-steps of loads are in flight per wave before the first MFMA of a group.
 // ---------------------------------------------------------------------------------------------------
@@ -93,19 +94,12 @@ __device__ __forceinline__ void skinny_group(const half_t *const (&wp)[NT], int 
                 acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][u], b[cb][u], acc[t][cb], 0, 0, 0);
 }
 
-// HBM feeds a CU at ~24 GB/s, so a weight matrix has to be spread over ALL 256 CUs to stream at chip
-// rate: small-N layers split K across workgroups too (gridDim.y = KS).  Each workgroup publishes its
-// fp32 partial tile with write-through (sc1) stores and takes a ticket; the last one to arrive adds
-// the KS partials in slice order (deterministic, independent of arrival order) and runs the epilogue.
 template <int NCB, int KSPLIT, int NT>
-__global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_kernel(SkinnyParams p, float *slabs,
-                                                                                      unsigned *tickets) {
+__global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_kernel(SkinnyParams p) {
     constexpr int NW = KSPLIT == 1 ? 2 : KSPLIT;  // waves per workgroup
     __shared__ f32x4 red[KSPLIT == 1 ? 1 : KSPLIT][NCB][64];
-    __shared__ int sh_last;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int KS = gridDim.y, ks = blockIdx.y;
     // tile base row of this wave
     const int n0 = KSPLIT == 1 ? (blockIdx.x * NW + w) * 16 * NT : blockIdx.x * 16;
     // epilogue operands (bias, residual) of the element this thread will own: fetched now, so their latency
@@ -119,7 +113,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
             if (p.epi == SK_RESID_F32) pre[1] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.out[0]) + (long)er * p.ldo + en);
         }
     }
-    const int kslice = p.K / (KSPLIT * KS), kbeg = KSPLIT == 1 ? 0 : (ks * KSPLIT + w) * kslice;
+    const int kslice = p.K / KSPLIT, kbeg = KSPLIT == 1 ? 0 : w * kslice;
     // weights: row-major [N][K] (a wave instruction = 16 rows x 64 B) or the tile-major repack (1 KiB contiguous)
     const half_t *wp[NT];
     const int wstep = p.Wt ? 512 : 32;
@@ -173,33 +167,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
 #pragma unroll
         for (int ww = 1; ww < KSPLIT; ww++) v += red[ww][cb][src_lane];
     }
-    if (KS == 1) {
-        if (owner) skinny_store(p, v, r, n0 + 4 * nq, can_pre, pre[0], pre[1]);
-        return;
-    }
-    // cross-workgroup split-K: slab[tile][ks][r][nq] (f32x4 as 4 write-through dwords)
-    float *slab = slabs + ((long)blockIdx.x * KS) * 64 * 16;
-    if (owner) {
-        float *dst = slab + ((long)ks * 64 + r) * 16 + 4 * nq;
-#pragma unroll
-        for (int i = 0; i < 4; i++) __hip_atomic_store(dst + i, v[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains before the ticket
-    __syncthreads();
-    if (tid == 0) {
-        unsigned t = __hip_atomic_fetch_add(tickets + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sh_last = (t == (unsigned)KS - 1);
-        if (sh_last) __hip_atomic_store(tickets + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!sh_last || !owner) return;
-    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int q = 0; q < KS; q++) {  // slice order, not arrival order; sc1 loads bypass this CU's L1
-        const float *src = slab + ((long)q * 64 + r) * 16 + 4 * nq;
-#pragma unroll
-        for (int i = 0; i < 4; i++) sum[i] += __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    skinny_store(p, sum, r, n0 + 4 * nq, can_pre, pre[0], pre[1]);
+    if (owner) skinny_store(p, v, r, n0 + 4 * nq, can_pre, pre[0], pre[1]);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -532,7 +500,7 @@ static void launch_skinny_ln(const SkinnyParams &p, hipStream_t st) {
 }
 
 template <int NCB>
-static void launch_skinny_ncb(const SkinnyParams &p, float *slabs, unsigned *tickets, hipStream_t st) {
+static void launch_skinny_ncb(const SkinnyParams &p, hipStream_t st) {
     const int tiles = (p.N + 15) / 16;
     if (p.ln_x && tiles < 2048) {  // the caller checked skinny_ln_supported: NCB <= 2
         if (NCB == 1) launch_skinny_ln<1>(p, st); else launch_skinny_ln<2>(p, st);
@@ -554,31 +522,30 @@ static void launch_skinny_ncb(const SkinnyParams &p, float *slabs, unsigned *tic
             hipLaunchKernelGGL((skinny_lds_kernel<NCB>), dim3(256), dim3(512), lds, st, p);
         } else {
             int waves = (tiles + 1) / 2;
-            hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 1, 2>), dim3((waves + 1) / 2), dim3(128), 0, st, p, slabs, tickets);
+            hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 1, 2>), dim3((waves + 1) / 2), dim3(128), 0, st, p);
         }
         return;
     }
-    // waves per workgroup (in-block split) x KS workgroups per tile: aim at >= 2 workgroups per CU-ish
-    // while every wave keeps a whole number of 32-deep k-steps
-    int ks = 1;
-    auto fits = [&](int nw, int k) { return p.K % (nw * k * 32) == 0; };
-    int nw = fits(4, 1) ? 4 : (fits(2, 1) ? 2 : 0);
-    if (slabs && tiles <= SKINNY_MAX_TILES && p.K >= 2560) {  // short-K layers: the ticket round trips cost more than they buy
-        while (tiles * ks < 320 && ks < 8 && nw && fits(nw, ks * 2)) ks *= 2;
-        if (tiles * ks < 320 && nw == 4 && fits(2, ks * 2) && ks < 8) { nw = 2; ks *= 2; }
-    }
-    if (nw == 4) hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 4, 1>), dim3(tiles, ks), dim3(256), 0, st, p, slabs, tickets);
-    else hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 2, 1>), dim3(tiles, ks), dim3(128), 0, st, p, slabs, tickets);
+    // waves per workgroup: every wave keeps a whole number of 32-deep k-steps, and at most ~10 of them (one group of
+    // loads in flight = one memory round trip per wave).  r01 split the long-K layer (fc2, K = 4 d) across workgroups
+    // instead (slab stores + ticket + slab loads: three more dependent round trips and cross-workgroup atomics for the
+    // same ~11 us); 16 waves of one workgroup meet in LDS.
+    auto fits = [&](int nw) { return p.K % (nw * 32) == 0; };
+    // (the slicing must not depend on the batch: one summation order for every NCB = bit-exact batch invariance)
+    if (p.K >= 2560 && fits(16)) hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 16, 1>), dim3(tiles), dim3(1024), 0, st, p);
+    else if (p.K >= 2560 && fits(8)) hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 8, 1>), dim3(tiles), dim3(512), 0, st, p);
+    else if (fits(4)) hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 4, 1>), dim3(tiles), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 2, 1>), dim3(tiles), dim3(128), 0, st, p);
 }
 
-void launch_skinny(const SkinnyParams &p_in, float *slabs, unsigned *tickets, hipStream_t st) {
+void launch_skinny(const SkinnyParams &p_in, hipStream_t st) {
     SkinnyParams p = p_in;
     p.ln_rk = 1.0f / (float)p.K;
     int ncb = (p.R + 15) / 16;
-    if (ncb <= 1) launch_skinny_ncb<1>(p, slabs, tickets, st);
-    else if (ncb == 2) launch_skinny_ncb<2>(p, slabs, tickets, st);
-    else if (ncb == 3) launch_skinny_ncb<3>(p, slabs, tickets, st);
-    else launch_skinny_ncb<4>(p, slabs, tickets, st);
+    if (ncb <= 1) launch_skinny_ncb<1>(p, st);
+    else if (ncb == 2) launch_skinny_ncb<2>(p, st);
+    else if (ncb == 3) launch_skinny_ncb<3>(p, st);
+    else launch_skinny_ncb<4>(p, st);
 }
 
 // ---------------------------------------------------------------------------------------------------

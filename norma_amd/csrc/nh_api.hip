@@ -72,8 +72,6 @@ struct nh_ctx {
     uint8_t *suppress = nullptr;
     float *lpart = nullptr;
     unsigned *ltick = nullptr;
-    float *sk_slabs = nullptr;
-    unsigned *sk_tickets = nullptr;
     int32_t *d_pos = nullptr;  // device-side decode position (hipGraph replays read it)
     hipGraphExec_t step_graph = nullptr;   // one decode step
     hipGraphExec_t multi_graph = nullptr;  // NH_GRAPH_STEPS consecutive steps (one launch gap instead of NH_GRAPH_STEPS)
@@ -281,7 +279,7 @@ extern "C" int nh_create(int device_ordinal, const nh_config *cfg, int max_batch
     DA(dxn, half_t, (long)B * d); DA(dq, half_t, (long)B * d); DA(datt, half_t, (long)B * d); DA(dhid, half_t, (long)B * 4 * d);
     DA(ds.tokens, int32_t, (long)B * ctxlen); DA(ds.n_tokens, int32_t, B); DA(ds.done, int32_t, B);
     DA(ds.have_last, int32_t, B); DA(ds.last_ts, int32_t, B); DA(ds.sum_logprob, double, B); DA(ds.no_speech, double, B);
-    DA(ds.n_active, int32_t, 1); DA(suppress, uint8_t, V); DA(lpart, float, (long)B * 64); DA(ltick, unsigned, B); DA(d_pos, int32_t, 4); DA(d_lang_tokens, int32_t, 256); DA(d_lang_out, int32_t, B); DA(d_lang_probs, float, (long)B * 256); DA(sk_slabs, float, (long)SKINNY_MAX_TILES * 8 * 64 * 16); DA(sk_tickets, unsigned, SKINNY_MAX_TILES);
+    DA(ds.n_active, int32_t, 1); DA(suppress, uint8_t, V); DA(lpart, float, (long)B * 64); DA(ltick, unsigned, B); DA(d_pos, int32_t, 4); DA(d_lang_tokens, int32_t, 256); DA(d_lang_out, int32_t, B); DA(d_lang_probs, float, (long)B * 256);
 #undef DA
     if (!ok) { ctx->err = "hipMalloc failed while sizing the context (out of device memory?)"; return bail(NH_ERR_NOMEM); }
     ctx->ds.suppress = ctx->suppress;
@@ -670,7 +668,7 @@ static void skinny(nh_ctx *ctx, const half_t *x, long ldx, const LinW &W, int R,
     p.pos_ptr = pos_ptr; p.ln_x = ln_x; p.ln_w = ln_w; p.ln_b = ln_b;
     p.x = x; p.ldx = ldx; p.W = W.w; p.Wt = W.wt; p.bias = W.b; p.R = R; p.N = N; p.K = K; p.epi = epi;
     p.out[0] = o0; p.out[1] = o1; p.out[2] = o2; p.ldo = ldo; p.d = ctx->c.d_model; p.t0 = t0; p.Tn = 1; p.ctx = ctxlen;
-    launch_skinny(p, ctx->sk_slabs, ctx->sk_tickets, ctx->sd);
+    launch_skinny(p, ctx->sd);
 }
 
 // every decoder LayerNorm uses the "sliced" summation tree (nh_kernels.h) when the width allows, so that the fused and

@@ -129,10 +129,7 @@ __device__ __forceinline__ f32x4 ln_apply(const f32x4 &x, float mean, float inv,
 #endif
 // stand-alone kernel with that arithmetic (K % 128 == 0, K <= 1280); returns false when the shape is not covered
 bool launch_layernorm_sliced(const float *x, const float *w, const float *b, half_t *y, float *y32, int M, int K, hipStream_t st);
-#define SKINNY_MAX_TILES 512
-// slabs: f32 [SKINNY_MAX_TILES][8][64][16] scratch for cross-workgroup split-K (nullptr: never split across
-// workgroups); tickets: u32 [SKINNY_MAX_TILES], zero-initialised, self-resetting
-void launch_skinny(const SkinnyParams &p, float *slabs, unsigned *tickets, hipStream_t st);
+void launch_skinny(const SkinnyParams &p, hipStream_t st);
 // out: ceil(N/16) * 16 * K halfs.  Tile-major: the MFMA A fragment of (16-row tile, 32-deep k-step) is 1 KiB contiguous, so a
 // GEMV streams its weights like a memcpy (the row-major form reads 16 x 64 B per wave instruction: 3.7 vs 5.1 TB/s).
 void launch_repack_tiles(const half_t *W, half_t *out, int N, int K, hipStream_t st);

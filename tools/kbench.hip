@@ -43,7 +43,6 @@ int main(int argc, char **argv) {
     float *logits = dmalloc<float>((size_t)B * VP), *lpart = dmalloc<float>(B * 64);
     unsigned *ltick = dmalloc<unsigned>(B);
     int32_t *pos = dmalloc<int32_t>(4); (void)pos;
-    float *slabs = dmalloc<float>((size_t)SKINNY_MAX_TILES * 8 * 64 * 16); if (argc > 2) { slabs = nullptr; printf("(cross-workgroup split-K disabled)\n"); } unsigned *tick = dmalloc<unsigned>(SKINNY_MAX_TILES);
     DecodeState ds{};
     ds.tokens = dmalloc<int32_t>((size_t)B * 4096); ds.n_tokens = dmalloc<int32_t>(B); ds.done = dmalloc<int32_t>(B);
     ds.have_last = dmalloc<int32_t>(B); ds.last_ts = dmalloc<int32_t>(B); ds.sum_logprob = dmalloc<double>(B);
@@ -53,20 +52,20 @@ int main(int argc, char **argv) {
     auto sk_call = [&](const half_t *xin, long ldx, half_t *W, int N, int K, int epi, void *o0, long ldo) {
         SkinnyParams p{}; p.x = xin; p.ldx = ldx; p.W = W; p.bias = bias; p.R = B; p.N = N; p.K = K; p.epi = epi;
         p.out[0] = o0; p.out[1] = sk; p.out[2] = sv; p.ldo = ldo; p.d = d; p.t0 = 5; p.Tn = 1; p.ctx = C;
-        launch_skinny(p, slabs, tick, st);
+        launch_skinny(p, st);
     };
     auto ln_call = [&](half_t *W, int N, int K, int epi, void *o0, long ldo) {  // LayerNorm fused into the GEMV
         SkinnyParams p{}; p.x = nullptr; p.ldx = K; p.W = W; p.bias = bias; p.R = B; p.N = N; p.K = K; p.epi = epi;
         p.out[0] = o0; p.out[1] = sk; p.out[2] = sv; p.ldo = ldo; p.d = d; p.t0 = 5; p.Tn = 1; p.ctx = C;
         p.ln_x = x; p.ln_w = lnw; p.ln_b = lnb;
-        launch_skinny(p, slabs, tick, st);
+        launch_skinny(p, st);
     };
     const int R = 100;
     if (skinny_ln_supported(B, 3 * d, d)) {
         bench("LN+qkv   N=3840 K=1280 (fused)", R, [&] { ln_call(W(3ul * d * d), 3 * d, d, SK_QKV, q, d); }, 3.0 * d * d * 2);
         bench("LN+cq    N=1280 K=1280 (fused)", R, [&] { ln_call(W(1ul * d * d), d, d, SK_F16, q, d); }, 1.0 * d * d * 2);
         bench("LN+fc1   N=5120 K=1280 (fused)", R, [&] { ln_call(W(4ul * d * d), 4 * d, d, SK_GELU_F16, hid, 4 * d); }, 4.0 * d * d * 2);
-        bench("LN+logits N=51866 K=1280 (fused)", 9, [&] { SkinnyParams p{}; p.ldx = d; p.W = W((size_t)V * d); p.R = B; p.N = V; p.K = d; p.epi = SK_F32; p.out[0] = logits; p.ldo = VP; p.ln_x = x; p.ln_w = lnw; p.ln_b = lnb; launch_skinny(p, slabs, tick, st); }, (double)V * d * 2);
+        bench("LN+logits N=51866 K=1280 (fused)", 9, [&] { SkinnyParams p{}; p.ldx = d; p.W = W((size_t)V * d); p.R = B; p.N = V; p.K = d; p.epi = SK_F32; p.out[0] = logits; p.ldo = VP; p.ln_x = x; p.ln_w = lnw; p.ln_b = lnb; launch_skinny(p, st); }, (double)V * d * 2);
     }
     {   // the same GEMVs on the tile-major repack of their weights
         half_t *wt = dmalloc<half_t>((size_t)((V + 15) / 16) * 16 * d);
@@ -77,7 +76,7 @@ int main(int argc, char **argv) {
                 SkinnyParams p{}; p.x = ln ? nullptr : (K == d ? xn : hid); p.ldx = K; p.W = Wr; p.Wt = wt; p.bias = epi == SK_F32 ? nullptr : bias; p.R = B; p.N = N; p.K = K; p.epi = epi;
                 p.out[0] = o0; p.out[1] = sk; p.out[2] = sv; p.ldo = ldo; p.d = d; p.t0 = 5; p.Tn = 1; p.ctx = C;
                 if (ln) { p.ln_x = x; p.ln_w = lnw; p.ln_b = lnb; }
-                launch_skinny(p, slabs, tick, st);
+                launch_skinny(p, st);
             }, (double)N * K * 2);
         };
         tiled("tiled LN+qkv   N=3840 K=1280", R, 3 * d, d, SK_QKV, q, d, true);
@@ -94,7 +93,7 @@ int main(int argc, char **argv) {
     bench("skinny cq    N=1280 K=1280 (F16)", R, [&] { sk_call(xn, d, W(1ul * d * d), d, d, SK_F16, q, d); }, 1.0 * d * d * 2);
     bench("skinny fc1   N=5120 K=1280 (GELU)", R, [&] { sk_call(xn, d, W(4ul * d * d), 4 * d, d, SK_GELU_F16, hid, 4 * d); }, 4.0 * d * d * 2);
     bench("skinny fc2   N=1280 K=5120 (RESID)", R, [&] { sk_call(hid, 4 * d, W(4ul * d * d), d, 4 * d, SK_RESID_F32, x, d); }, 4.0 * d * d * 2);
-    bench("skinny logits N=51866 K=1280 (F32)", 9, [&] { SkinnyParams p{}; p.x = xn; p.ldx = d; p.W = W((size_t)V * d); p.R = B; p.N = V; p.K = d; p.epi = SK_F32; p.out[0] = logits; p.ldo = VP; launch_skinny(p, slabs, tick, st); }, (double)V * d * 2);
+    bench("skinny logits N=51866 K=1280 (F32)", 9, [&] { SkinnyParams p{}; p.x = xn; p.ldx = d; p.W = W((size_t)V * d); p.R = B; p.N = V; p.K = d; p.epi = SK_F32; p.out[0] = logits; p.ldo = VP; launch_skinny(p, st); }, (double)V * d * 2);
     bench("dec_attn self Tk=200", R, [&] { launch_dec_attention(q, sk, sv, att, B, 1, H, d, C, 200, nullptr, st); }, 2.0 * B * 200 * d * 2);
     bench("dec_attn cross Tk=1500", 9, [&] { size_t o = (size_t)(kvr++ % 3) * B * S * d; launch_dec_attention(q, kc + o, vc + o, att, B, 1, H, d, S, S, nullptr, st); }, 2.0 * B * S * d * 2);
     bench("dec_attn cross Tk=1500, head-major K/V", 9, [&] { size_t o = (size_t)(kvr++ % 3) * B * S * d; launch_dec_attention(q, kc + o, vc + o, att, B, 1, H, d, S, S, nullptr, st, 1); }, 2.0 * B * S * d * 2);

@@ -35,11 +35,11 @@ int main() {
             // (a) stand-alone LN, plain GEMM
             if (!launch_layernorm_sliced(dx, dg, db, dxn, nullptr, R, K, st)) { printf("sliced LN does not cover K=%d\n", K); return 1; }
             p.x = dxn; p.ldx = K; p.out[0] = o1;
-            launch_skinny(p, nullptr, nullptr, st);
+            launch_skinny(p, st);
             // (b) fused
             if (!skinny_ln_supported(R, N, K)) { printf("R=%d N=%d K=%d: fusion not supported\n", R, N, K); continue; }
             p.x = nullptr; p.ln_x = dx; p.ln_w = dg; p.ln_b = db; p.out[0] = o2;
-            launch_skinny(p, nullptr, nullptr, st);
+            launch_skinny(p, st);
             CK(hipStreamSynchronize(st));
             std::vector<half_t> h1((size_t)R * N), h2((size_t)R * N);
             CK(hipMemcpy(h1.data(), o1, h1.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), o2, h2.size() * 2, hipMemcpyDeviceToHost));
