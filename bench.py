@@ -54,10 +54,11 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU (workload b32)")
     ap.add_argument("--max-new-tokens", type=int, default=0,
                     help="0 = reference behaviour (random weights run to the 447-token cap)")
-    ap.add_argument("--pipelines", type=int, default=int(os.environ.get("NORMA_BENCH_PIPELINES", "1")),
-                    help="batches in flight per GPU: each pipeline is its own context/stream; encoders are "
-                         "serialised by a host lock, decodes of other batches overlap them")
-    ap.add_argument("--no-pipelined-extra", action="store_true")
+    ap.add_argument("--pipelines", type=int, default=int(os.environ.get("NORMA_BENCH_PIPELINES", "3")),
+                    help="batches in flight per GPU (workload b32): each pipeline is its own context + host thread; "
+                         "encoders are serialised by a host lock, the latency-bound decode of one batch runs beside the "
+                         "MFMA-bound encoder of the next.  1 = one batch at a time")
+    ap.add_argument("--no-single-extra", action="store_true", help="skip the one-batch-at-a-time measurement in `extra`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-new-tokens", type=int, default=96)
     ap.add_argument("--dry-run", action="store_true",
@@ -214,12 +215,10 @@ def worker(args):
         raise RuntimeError("bench.py needs an MI355X; norma_amd has no CPU fallback")
 
     t_build = time.time()
-    P = max(1, args.pipelines)
+    P = max(1, args.pipelines) if job_chunks is None else 1   # the strong workloads run their job once per step
     headline = args.workload == "b32" and args.model is None
-    # extra (untimed by the contract) measurement at N=1: 3 batches in flight, see DESIGN.md 5
-    P_extra = 3 if (headline and world == 1 and P == 1 and not args.no_pipelined_extra) else 0
     hms = []
-    for _ in range(max(P, P_extra)):
+    for _ in range(P):
         h = hip.HipWhisper(cfg, device=local_rank, max_batch=max(B, 1))
         h.set_mel_filters(assets_io.mel_filters(cfg.num_mel_bins))
         h.set_tokens(tk, -1 if multilingual else tk.en, tk.transcribe)
@@ -305,7 +304,8 @@ def worker(args):
     res = run_steps(args.steps, args.max_new_tokens)
     barrier()
     dt = time.perf_counter() - t0
-    tm = hm.timings() if B else None
+    tm_timed = hm.timings() if B else None    # last step of pipeline 0 inside the timed region (GEMM launch events)
+    tm = tm_timed
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -314,17 +314,22 @@ def worker(args):
     value = audio_s / dt
 
     extra = {}
-    if P_extra:
-        # throughput with several batches in flight on one GPU: the latency-bound decode of one batch runs beside
-        # the MFMA-bound encoder of the next (encoders serialised by a host lock).  Not the headline `value`:
-        # kernels then share the GPU and their per-launch durations no longer describe the kernel alone.
-        n_x = 9
-        run_steps(P_extra, args.max_new_tokens, P=P_extra)
+    single_ms = dt / args.steps * 1e3     # wall time of a step with one batch on the GPU (the H2D comparison below)
+    if P > 1 and B:
+        # one batch at a time, untimed by the contract: the per-phase times (and their roofline fractions below) are taken
+        # from this pass, where no other batch shares the GPU; with several batches in flight a phase's wall time
+        # includes the kernels of the other batches interleaved with it
+        step(args.max_new_tokens, hm, pipelined=False)
         barrier()
-        tx = time.perf_counter()
-        run_steps(n_x, args.max_new_tokens, P=P_extra)
-        barrier()
-        extra["xrt_3_batches_in_flight_per_gpu"] = n_x * B * 30.0 / (time.perf_counter() - tx)
+        if not args.no_single_extra:
+            n1 = 3
+            t1 = time.perf_counter()
+            for _ in range(n1):
+                step(args.max_new_tokens, hm, pipelined=False)
+            barrier()
+            single_ms = (time.perf_counter() - t1) / n1 * 1e3
+            extra["xrt_one_batch_at_a_time_per_gpu"] = B * 30.0 / (single_ms * 1e-3)
+        tm = hm.timings()
     if headline and world == 1:
         # second decode-length protocol: 128 new tokens per clip, untimed by the contract
         if args.max_new_tokens == 0:
@@ -346,9 +351,11 @@ def worker(args):
         barrier()
         dth = (time.perf_counter() - t2) / n_h
         extra["xrt_host_pcm_per_gpu"] = B * 30.0 / dth
-        extra["h2d_pcm_ms_per_step"] = max(0.0, dth * 1e3 - dt / args.steps * 1e3)
+        extra["h2d_pcm_ms_per_step"] = max(0.0, dth * 1e3 - single_ms)
         hm.transcribe_batch_device(pcm_dev.data_ptr(), n_samples, synth.N_SAMPLES, args.max_new_tokens)  # timings() of a plain step again
         tm = hm.timings()
+        if P == 1:
+            tm_timed = tm
 
     if rank == 0:
         # HBM traffic of the dominant kernel per launch: from the committed rocprofv3 PMC passes (FETCH_SIZE and
@@ -363,7 +370,7 @@ def worker(args):
             traffic = sum(v["hbm_bytes_corrected"] * v["launches"] for v in rows) / nl if nl else None
         except Exception:
             traffic = None
-        gemm_tflops = tm["gemm_flops"] / (tm["gemm_ms"] * 1e-3) / 1e12 if tm and tm["gemm_ms"] > 0 else 0.0
+        gemm_tflops = tm_timed["gemm_flops"] / (tm_timed["gemm_ms"] * 1e-3) / 1e12 if tm_timed and tm_timed["gemm_ms"] > 0 else 0.0
         n_tok = int(np.mean([len(r["tokens"]) for r in res])) if res else 0
         # per-phase roofline fractions of the last timed step of rank 0 (algorithmic work / phase time / nominal peak)
         phases = []
@@ -407,9 +414,11 @@ def worker(args):
                          "unit": "TFLOP/s", "frac": gemm_tflops / MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_note": "bytes per launch from profiles/pmc_hbm_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
                                          "Infinity-Cache hits included; last profiled value, not live)",
-                         "launches": tm["gemm_launches"] if tm else 0,
-                         "avg_launch_ms": tm["gemm_ms"] / max(tm["gemm_launches"], 1) if tm else None,
-                         "flops_per_step": tm["gemm_flops"] if tm else None,
+                         "launches": tm_timed["gemm_launches"] if tm_timed else 0,
+                         "avg_launch_ms": tm_timed["gemm_ms"] / max(tm_timed["gemm_launches"], 1) if tm_timed else None,
+                         "flops_per_step": tm_timed["gemm_flops"] if tm_timed else None,
+                         "phases_note": "per-phase times of a step with ONE batch on the GPU" + (" (measured after the timed region; "
+                                        f"the timed region keeps {P} batches in flight)" if P > 1 else ""),
                          "phases": phases, "time_weighted_frac": time_weighted},
             "extra": extra, "model_build_s": t_build,
         }

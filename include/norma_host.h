@@ -74,10 +74,25 @@ void nm_model_enable_language_detection(nm_model *m, const int32_t *lang_tokens,
 /* GGUF reader check (no GPU needed): writes one line per tensor "name type d0xd1.. sum_of_dequantised_values\n" into buf,
  * returns the number of tensors or -1 (message in buf). */
 int nm_gguf_list(const char *path, char *buf, int cap);
+/* i-th language code in Language::iter() order (languages.rs:7-107, used at model.rs:204 and multilingual.rs:395-398);
+ * NULL past the 99th.  The language token is "<|code|>". */
+const char *nm_language_code(int i);
+/* The asset readers alone (no GPU): tokenizer.json (Tokenizer::from_file, token_to_id, decode -- monolingual.rs:349,
+ * mod.rs:86-90, model.rs:147) and safetensors (VarBuilder::from_mmaped_safetensors, monolingual.rs:237-239). */
+typedef struct nm_tokenizer nm_tokenizer;
+nm_tokenizer *nm_tokenizer_open(const char *path, char *err, int err_len);
+void nm_tokenizer_free(nm_tokenizer *t);
+int nm_tokenizer_token_to_id(const nm_tokenizer *t, const char *token); /* -1 = whisper::Error::TokenId */
+/* writes the UTF-8 text (NUL-terminated, truncated to cap - 1) and returns its full length in bytes */
+int nm_tokenizer_decode(const nm_tokenizer *t, const uint32_t *ids, size_t n, int skip_special_tokens, char *buf, int cap);
+/* one line per tensor "name dtype d0xd1.. sum sum_abs\n" (f64 sums of the values widened to f32); returns the number of
+ * tensors or -1 with the message in buf.  F32, F16 and BF16 are read. */
+int nm_safetensors_list(const char *path, char *buf, int cap);
 int nm_model_language_token(const nm_model *m); /* current language token, -1 = not detected yet */
-/* decode_with_fallback's sampled attempts at t = 0.2 .. 1.0 (model.rs:175-188).  Off by default: the t = 0 result is
- * returned and nm_model_last_result reports needed_fallback.  On: the reference's loop, drawing under the seeded
- * sampling contract of norma_hip.h (the reference seeds from entropy, so draws cannot match, only their distribution). */
+/* decode_with_fallback's sampled attempts at t = 0.2 .. 1.0 (model.rs:175-188).  ON by default with an entropy seed, as in the
+ * reference (StdRng::from_entropy): a slice whose every attempt has avg_logprob < -1 is dropped.  enable = 1 with a seed
+ * fixes the draws (seeded sampling contract of norma_hip.h; the reference's draws cannot be reproduced, only their
+ * distribution); enable = 0 returns the t = 0 result and nm_model_last_result reports needed_fallback. */
 void nm_model_set_temperature_fallback(nm_model *m, int enable, uint64_t seed);
 /* text of the last nm_model_transcribe call (empty without a tokenizer); returns its length */
 int nm_model_last_text(const nm_model *m, char *buf, int cap);

@@ -570,7 +570,11 @@ __device__ __forceinline__ void merge_part(AttnPart &a, float mo, float lo, cons
 __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict__ q, const half_t *__restrict__ kc,
                                                        const half_t *__restrict__ vc, half_t *__restrict__ out,
                                                        int d, int ctx, int Tk, const int32_t *__restrict__ pos_ptr,
-                                                       int kv_head_major) {
+                                                       int kv_head_major, const int32_t *__restrict__ done) {
+    // a finished sequence (eot, cap, or the no-speech exit) no longer streams its K/V: the reference's loop ends per
+    // sequence at eot (model.rs:317); in a batch the others go on, and 0.49 GB of the 0.72 GB a step streams is per-sequence
+    // cross K/V.  Its attention row is left as it was; every later product is row-wise, nothing of it reaches another row.
+    if (done && done[blockIdx.y]) return;
     if (pos_ptr) Tk = *pos_ptr + 1;
     __shared__ float part[4][8][10];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -656,9 +660,10 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict_
 }
 
 void launch_dec_attention(const half_t *q, const half_t *kc, const half_t *vc, half_t *out, int B, int Tn,
-                          int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st, int kv_head_major) {
+                          int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st, int kv_head_major,
+                          const int32_t *done) {
     (void)Tn;  // one new position per sequence; its visible keys are exactly Tk (or *pos_ptr + 1)
-    hipLaunchKernelGGL(dec_attn_kernel, dim3(H, B), dim3(256), 0, st, q, kc, vc, out, d, ctx, Tk, pos_ptr, kv_head_major);
+    hipLaunchKernelGGL(dec_attn_kernel, dim3(H, B), dim3(256), 0, st, q, kc, vc, out, d, ctx, Tk, pos_ptr, kv_head_major, done);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -692,15 +692,17 @@ static void ln_skinny(nh_ctx *ctx, const LnW &ln, const LinW &W, int R, int N, i
 // one decoder position for the whole batch: consumes tokens[b][pos], leaves the residual stream in dx.
 // final_ln: also LN(dx) -> dxn (fp16) / dy32 (f32) (the teacher-forced view; the step path fuses it into the logits).
 // pos_ptr != nullptr: the position comes from device memory (the step is being captured into a hipGraph).
-static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr, bool final_ln = true) {
+// skip_done: finished sequences skip their attention (only inside decode_impl, where ds.done is live).
+static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr, bool final_ln = true, bool skip_done = false) {
+    const int32_t *done = skip_done ? ctx->ds.done : nullptr;
     const int d = ctx->c.d_model, B = ctx->cur_batch, H = ctx->c.decoder_attention_heads, C = ctx->c.max_target_positions;
     launch_embed(ctx->ds.tokens, C, ctx->tok_emb, ctx->dec_pos, ctx->dx, B, 1, pos, pos_ptr, d, ctx->sd);
     for (auto &L : ctx->dec) {
         ln_skinny(ctx, L.ln1, L.qkv, B, 3 * d, d, SK_QKV, ctx->dq, L.sk, L.sv, d, pos, C, pos_ptr);
-        launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos_ptr, ctx->sd, 1);  // head-major cache
+        launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos_ptr, ctx->sd, 1, done);  // head-major cache
         skinny(ctx, ctx->datt, d, L.o, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
         ln_skinny(ctx, L.ln2, L.cq, B, d, d, SK_F16, ctx->dq, nullptr, nullptr, d, 0, C, nullptr);
-        launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, nullptr, ctx->sd, 1);  // head-major cross K/V
+        launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, nullptr, ctx->sd, 1, done);  // head-major cross K/V
         skinny(ctx, ctx->datt, d, L.co, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
         ln_skinny(ctx, L.ln3, L.fc1, B, 4 * d, d, SK_GELU_F16, ctx->dhid, nullptr, nullptr, 4 * d, 0, C, nullptr);
         skinny(ctx, ctx->dhid, 4 * d, L.fc2, B, d, 4 * d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
@@ -762,7 +764,7 @@ static int decode_impl(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *resul
     // Prompt phase (eager): position pos consumes tokens[pos]; pos 0 also yields no_speech_prob
     // (model.rs:293-305: logits at position 0 of the flush = true pass).
     for (int pos = 0; pos < P - 1; pos++) {
-        decoder_step(ctx, pos);
+        decoder_step(ctx, pos, nullptr, true, true);
         steps++;
         if (pos == 0) {
             logits_from_dxn(ctx, B);
@@ -781,7 +783,7 @@ static int decode_impl(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *resul
             hipError_t ge = hipStreamBeginCapture(ctx->sd, hipStreamCaptureModeThreadLocal);
             if (ge != hipSuccess) return ctx->fail(NH_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(ge));
             for (int i = 0; i < (which ? NH_GRAPH_STEPS : 1); i++) {  // every step reads and advances the device-side position
-                decoder_step(ctx, 0, ctx->d_pos, false);
+                decoder_step(ctx, 0, ctx->d_pos, false, true);
                 logits_from_dx(ctx, B);
                 launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, ctx->d_pos, ctx->sd);
             }
@@ -808,7 +810,7 @@ static int decode_impl(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *resul
     for (int pos = first_pos; pos <= cap - 2;) {
         int n = 1;
         if (no_graph) {
-            decoder_step(ctx, pos, nullptr, false);
+            decoder_step(ctx, pos, nullptr, false, true);
             logits_from_dx(ctx, B);
             if (inv_t > 0.f) launch_sample_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, inv_t, seed, clip0, attempt, ctx->sd);
             else launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, nullptr, ctx->sd);

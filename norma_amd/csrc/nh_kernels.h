@@ -170,8 +170,10 @@ void launch_enc_attention(const half_t *q, const half_t *k, long ld, const half_
 // q: fp16 [B*Tn][d]; kc,vc: fp16 [B][ctx][d]; keys visible to new row i: t0 + i + 1 (causal) or Tk (cross)
 // pos_ptr != nullptr: causal self-attention over *pos_ptr + 1 keys (device-side position)
 // kv_head_major: K/V are [b][h][ctx][64] (the cross K/V written with GemmParams::head_major) instead of [b][ctx][d]
+// done: optional i32 [B]; sequences with done[b] != 0 are skipped (their output row is left untouched)
 void launch_dec_attention(const half_t *q, const half_t *kc, const half_t *vc, half_t *out, int B, int Tn,
-                          int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st, int kv_head_major = 0);
+                          int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st, int kv_head_major = 0,
+                          const int32_t *done = nullptr);
 
 // ---- logit processor: softmax + norma rules + argmax + bookkeeping -----------------------------------
 struct DecodeState {        // all device pointers

@@ -162,15 +162,34 @@ class MappedFile {
 };
 
 // ---- safetensors: u64 header length, JSON header {name: {dtype, shape, data_offsets}}, raw little-endian data ---
-struct StTensor { std::string name; std::string dtype; std::vector<int64_t> shape; const void *data; size_t bytes; };
+struct StTensor {
+    std::string name; std::string dtype; std::vector<int64_t> shape; const void *data; size_t bytes;
+    size_t n_elem() const { size_t n = 1; for (int64_t d : shape) n *= (size_t)d; return n; }
+};
+// bytes per element of the dtypes a Whisper checkpoint can hold (candle's VarBuilder casts any of them to m::DTYPE = f32)
+inline size_t st_elem_size(const std::string &dt) { return dt == "F32" ? 4 : (dt == "F16" || dt == "BF16") ? 2 : 0; }
+// widen one tensor to f32 (F32 copy, F16 / BF16 exact)
+inline bool st_to_f32(const StTensor &t, std::vector<float> &out) {
+    const size_t n = t.n_elem();
+    out.resize(n);
+    if (t.dtype == "F32") memcpy(out.data(), t.data, n * 4);
+    else if (t.dtype == "F16") { const _Float16 *h = reinterpret_cast<const _Float16 *>(t.data); for (size_t i = 0; i < n; i++) out[i] = (float)h[i]; }
+    else if (t.dtype == "BF16") {
+        const uint16_t *h = reinterpret_cast<const uint16_t *>(t.data);
+        for (size_t i = 0; i < n; i++) { uint32_t u = (uint32_t)h[i] << 16; memcpy(&out[i], &u, 4); }
+    } else return false;
+    return true;
+}
 
+// A checkpoint is untrusted input: every size the file declares is checked against the mapping before use (header length,
+// data offsets, and bytes == prod(shape) * sizeof(dtype)), with overflow-safe arithmetic.
 class SafeTensors {
   public:
     bool open(const std::string &path, std::string &err) {
         if (!f_.open(path, err)) return false;
         if (f_.size() < 8) { err = "safetensors: file too small"; return false; }
         uint64_t hl; memcpy(&hl, f_.data(), 8);
-        if (8 + hl > f_.size()) { err = "safetensors: bad header length"; return false; }
+        if (hl > f_.size() - 8) { err = "safetensors: bad header length"; return false; }
         Json h; JsonParser jp(f_.data() + 8, (size_t)hl);
         if (!jp.parse(h) || h.type != Json::Obj) { err = "safetensors: " + jp.error; return false; }
         const char *base = f_.data() + 8 + hl;
@@ -178,11 +197,21 @@ class SafeTensors {
         for (auto &kv : h.obj) {
             if (kv.first == "__metadata__") continue;
             const Json *dt = kv.second.get("dtype"), *sh = kv.second.get("shape"), *off = kv.second.get("data_offsets");
-            if (!dt || !sh || !off || off->arr.size() != 2) { err = "safetensors: malformed entry " + kv.first; return false; }
+            if (!dt || !sh || !off || dt->type != Json::Str || sh->type != Json::Arr || off->arr.size() != 2) { err = "safetensors: malformed entry " + kv.first; return false; }
             StTensor t; t.name = kv.first; t.dtype = dt->str;
-            for (auto &d : sh->arr) t.shape.push_back((int64_t)d.num);
+            size_t n = 1;
+            for (auto &d : sh->arr) {
+                if (d.type != Json::Num || d.num < 0 || d.num > 9e15) { err = "safetensors: bad shape for " + kv.first; return false; }
+                const size_t dim = (size_t)d.num;
+                if (dim != 0 && n > (size_t)-1 / dim) { err = "safetensors: shape overflows for " + kv.first; return false; }
+                n *= dim;
+                t.shape.push_back((int64_t)dim);
+            }
+            if (off->arr[0].num < 0 || off->arr[1].num < 0 || off->arr[0].num > 9e15 || off->arr[1].num > 9e15) { err = "safetensors: bad offsets for " + kv.first; return false; }
             size_t b = (size_t)off->arr[0].num, e = (size_t)off->arr[1].num;
             if (e < b || e > avail) { err = "safetensors: offsets out of range for " + kv.first; return false; }
+            const size_t es = st_elem_size(t.dtype);
+            if (es && (n > (size_t)-1 / es || e - b != n * es)) { err = "safetensors: " + kv.first + " declares " + std::to_string(n) + " " + t.dtype + " elements over " + std::to_string(e - b) + " bytes"; return false; }
             t.data = base + b; t.bytes = e - b;
             tensors.push_back(std::move(t));
         }
@@ -227,7 +256,11 @@ class GgufFile {
             if (!rd_str(t.name) || !rd(nd) || nd > 4) { err = "gguf: truncated tensor info"; return false; }
             std::vector<uint64_t> ne(nd);
             t.n_elem = 1;
-            for (uint32_t d = 0; d < nd; d++) { if (!rd(ne[d])) { err = "gguf: truncated dims"; return false; } t.n_elem *= (size_t)ne[d]; }
+            for (uint32_t d = 0; d < nd; d++) {
+                if (!rd(ne[d])) { err = "gguf: truncated dims"; return false; }
+                if (ne[d] != 0 && t.n_elem > ((size_t)1 << 40) / ne[d]) { err = "gguf: element count of " + t.name + " overflows"; return false; }
+                t.n_elem *= (size_t)ne[d];
+            }
             for (uint32_t d = 0; d < nd; d++) t.shape.push_back((int64_t)ne[nd - 1 - d]);   // ggml lists the contiguous dim first
             if (!rd(t.type) || !rd(off)) { err = "gguf: truncated tensor info"; return false; }
             if (t.type == 8 && (nd == 0 || ne[0] % 32 != 0)) { err = "gguf: Q8_0 tensor " + t.name + " with a row length that is not a multiple of 32"; return false; }
@@ -243,7 +276,7 @@ class GgufFile {
             else if (t.type == 1) bytes = t.n_elem * 2;
             else if (t.type == 8) bytes = t.n_elem / 32 * 34;
             else { err = "gguf: unsupported ggml type " + std::to_string(t.type) + " for " + t.name; return false; }
-            if (base + offs[i] + bytes > f_.size()) { err = "gguf: data of " + t.name + " runs past the end of the file"; return false; }
+            if (base > f_.size() || offs[i] > f_.size() - base || bytes > f_.size() - base - offs[i]) { err = "gguf: data of " + t.name + " runs past the end of the file"; return false; }
             t.data = f_.data() + base + offs[i];
         }
         return true;
@@ -334,11 +367,14 @@ class TokenizerJson {
     }
     // Tokenizer::token_to_id (whisper/mod.rs:86-90); -1 = Error::TokenId
     int token_to_id(const std::string &tok) const { auto it = tok_to_id_.find(tok); return it == tok_to_id_.end() ? -1 : it->second; }
-    // Tokenizer::decode(ids, skip_special_tokens = true) for a ByteLevel BPE model
-    std::string decode(const uint32_t *ids, size_t n) const {
+    // Tokenizer::decode(ids, skip_special_tokens) for a ByteLevel BPE model: special added tokens are dropped when asked,
+    // the remaining token strings are mapped back to bytes (GPT-2 bytes_to_unicode) and the byte string is turned into
+    // text like Rust's String::from_utf8_lossy does (the ByteLevel decoder of the `tokenizers` crate): every maximal
+    // invalid sequence becomes U+FFFD.
+    std::string decode(const uint32_t *ids, size_t n, bool skip_special = true) const {
         std::string bytes;
         for (size_t i = 0; i < n; i++) {
-            if (ids[i] >= id_to_tok_.size() || special_[ids[i]]) continue;
+            if (ids[i] >= id_to_tok_.size() || (skip_special && special_[ids[i]])) continue;
             const std::string &t = id_to_tok_[ids[i]];
             for (size_t p = 0; p < t.size();) {  // UTF-8 code points -> original bytes
                 unsigned c = (unsigned char)t[p], cp; int len;
@@ -350,7 +386,35 @@ class TokenizerJson {
                 if (it != uni_to_byte_.end()) bytes += (char)it->second;
             }
         }
-        return bytes;
+        return utf8_lossy(bytes);
+    }
+    // String::from_utf8_lossy: valid sequences are kept; each maximal invalid prefix (per the Unicode "substitution of
+    // maximal subparts" rule Rust follows) is replaced by one U+FFFD
+    static std::string utf8_lossy(const std::string &b) {
+        std::string out;
+        const size_t n = b.size();
+        size_t i = 0;
+        auto cont = [&](size_t k, unsigned lo, unsigned hi) { return k < n && (unsigned char)b[k] >= lo && (unsigned char)b[k] <= hi; };
+        while (i < n) {
+            const unsigned c = (unsigned char)b[i];
+            size_t len = 0;   // length of a valid sequence starting here, or 0
+            size_t bad = 1;   // bytes consumed by one replacement when invalid
+            if (c < 0x80) len = 1;
+            else if (c >= 0xC2 && c <= 0xDF) { if (cont(i + 1, 0x80, 0xBF)) len = 2; }
+            else if (c >= 0xE0 && c <= 0xEF) {
+                const unsigned lo = c == 0xE0 ? 0xA0 : 0x80, hi = c == 0xED ? 0x9F : 0xBF;
+                if (cont(i + 1, lo, hi)) { if (cont(i + 2, 0x80, 0xBF)) len = 3; else bad = 2; }
+            } else if (c >= 0xF0 && c <= 0xF4) {
+                const unsigned lo = c == 0xF0 ? 0x90 : 0x80, hi = c == 0xF4 ? 0x8F : 0xBF;
+                if (cont(i + 1, lo, hi)) {
+                    if (cont(i + 2, 0x80, 0xBF)) { if (cont(i + 3, 0x80, 0xBF)) len = 4; else bad = 3; }
+                    else bad = 2;
+                }
+            }
+            if (len) { out.append(b, i, len); i += len; }
+            else { out += "\xEF\xBF\xBD"; i += bad; }
+        }
+        return out;
     }
     size_t size() const { return id_to_tok_.size(); }
   private:

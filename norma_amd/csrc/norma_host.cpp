@@ -105,6 +105,45 @@ int nm_gguf_list(const char *path, char *buf, int cap) {
     return (int)g.tensors.size();
 }
 
+// Language::iter() order (languages.rs:7-107): code i of the table the host layer resolves "<|code|>" tokens from
+const char *nm_language_code(int i) { return i >= 0 && i < 99 ? LANGUAGE_CODES[i] : nullptr; }
+
+// ---- asset readers alone (no GPU): what tests/test_assets_cpu.py pins against fixtures written by the `tokenizers` and
+// `safetensors` Python bindings of the crates the reference uses (model.rs:147, mod.rs:86-90, monolingual.rs:237-239)
+struct nm_tokenizer { norma::assets::TokenizerJson t; };
+nm_tokenizer *nm_tokenizer_open(const char *path, char *err, int err_len) {
+    auto *t = new nm_tokenizer();
+    std::string e;
+    if (!path || !t->t.load(path, e)) { put_err(err, err_len, e.empty() ? "nm_tokenizer_open: no path" : e); delete t; return nullptr; }
+    return t;
+}
+void nm_tokenizer_free(nm_tokenizer *t) { delete t; }
+int nm_tokenizer_token_to_id(const nm_tokenizer *t, const char *token) { return t && token ? t->t.token_to_id(token) : -1; }
+int nm_tokenizer_decode(const nm_tokenizer *t, const uint32_t *ids, size_t n, int skip_special_tokens, char *buf, int cap) {
+    if (!t) return -1;
+    const std::string s = t->t.decode(ids, n, skip_special_tokens != 0);
+    if (buf && cap > 0) { const size_t m = s.size() < (size_t)cap - 1 ? s.size() : (size_t)cap - 1; memcpy(buf, s.data(), m); buf[m] = 0; }
+    return (int)s.size();
+}
+
+int nm_safetensors_list(const char *path, char *buf, int cap) {
+    norma::assets::SafeTensors st; std::string err;
+    if (!path || !st.open(path, err)) { put_err(buf, cap, err.empty() ? "nm_safetensors_list: no path" : err); return -1; }
+    std::string out;
+    for (const auto &t : st.tensors) {
+        std::vector<float> v;
+        double s = 0, sa = 0;
+        if (norma::assets::st_to_f32(t, v)) for (float x : v) { s += x; sa += x < 0 ? -(double)x : (double)x; }
+        out += t.name + " " + t.dtype + " ";
+        for (size_t i = 0; i < t.shape.size(); i++) out += (i ? "x" : "") + std::to_string(t.shape[i]);
+        if (t.shape.empty()) out += "scalar";
+        char num[96]; snprintf(num, sizeof num, " %.17g %.17g\n", s, sa);
+        out += num;
+    }
+    put_err(buf, cap, out);
+    return (int)st.tensors.size();
+}
+
 void nm_model_set_temperature_fallback(nm_model *m, int enable, uint64_t seed) {
     if (m && m->m) m->m->set_temperature_fallback(enable != 0, seed);
 }

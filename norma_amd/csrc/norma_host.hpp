@@ -22,6 +22,7 @@
 
 #include <algorithm>
 #include <functional>
+#include <random>
 #include <string>
 #include <utility>
 #include <vector>
@@ -160,9 +161,8 @@ class Model {
             if (e) return e;
             if (!have) { drain(slice_len); continue; }                // :90-93
             if (dr.no_speech_prob > NO_SPEECH_THRESHOLD && dr.avg_logprob < LOGPROB_THRESHOLD) { drain(slice_len); continue; }  // :95-98
-            bool drained = false, any = false;
+            bool drained = false;
             for (auto seg : inclusive_boxed_by(dr.tokens, [&](uint32_t t) { return t > (uint32_t)tk_.no_timestamps || t == (uint32_t)tk_.eot; })) {
-                any = true;
                 const uint32_t *tok = dr.tokens.data() + seg.first;
                 const size_t n = seg.second - seg.first;
                 const uint32_t s_timestamp = tok[0] - (uint32_t)tk_.no_timestamps - 1;  // :103
@@ -185,10 +185,9 @@ class Model {
                 out.push_back(std::move(sg));
             }
             // H1: a result without any drained segment (e.g. the no-speech early return, whose
-            // tokens hold no timestamp) leaves `buf` untouched in the reference, which then spins forever on the
-            // same slice.  Deviation: drain the slice and go on.
-            if (!stop && !drained && !any) drain(slice_len);
-            else if (!stop && !drained) drain(slice_len);
+            // tokens hold no timestamp, or segments that all close on a timestamp) leaves `buf` untouched in the
+            // reference, which then spins forever on the same slice.  Deviation: drain the slice and go on.
+            if (!stop && !drained) drain(slice_len);
         }
         if (final_chunk) {                                            // :153-156
             if (detect_) lang_token_ = -1;                            // self.lang.clear()
@@ -200,9 +199,11 @@ class Model {
 
     // decode_with_fallback (model.rs:164-191).  The t = 0 pass is deterministic.  The sampled attempts (t = 0.2 .. 1.0)
     // draw from an entropy-seeded RNG in the reference (monolingual.rs:433-439) and cannot be reproduced draw for draw;
-    // here they follow the seeded sampling contract of include/norma_hip.h (same distribution).  They are OFF until
-    // set_temperature_fallback(true, seed) is called: then this is the reference's loop; while off, the t = 0 result is
-    // returned even when the reference would have gone on, and last_needed_fallback() says so.
+    // here they follow the seeded sampling contract of include/norma_hip.h (same distribution).  Default = the
+    // reference's behaviour: the loop is ON and the seed comes from std::random_device (StdRng::from_entropy), so a
+    // hopeless slice is dropped exactly when the reference would drop it.  set_temperature_fallback(true, seed) fixes the
+    // seed (reproducible tests); set_temperature_fallback(false, _) returns the t = 0 result even when the reference would
+    // have gone on, and last_needed_fallback() says so.
     void set_temperature_fallback(bool enable, uint64_t seed) { fallback_ = enable; seed_ = seed; slices_ = 0; }
     Error decode_with_fallback(const float *pcm, size_t n, DecodingResult &dr, bool &have) {
         int32_t ns = (int32_t)n;
@@ -236,6 +237,7 @@ class Model {
     bool last_needed_fallback() const { return needs_fallback_; }
 
   private:
+    static uint64_t entropy_seed() { std::random_device rd; return ((uint64_t)rd() << 32) ^ (uint64_t)rd(); }  // StdRng::from_entropy, monolingual.rs:433
     void drain(size_t n) { buf_.erase(buf_.begin(), buf_.begin() + (long)std::min(n, buf_.size())); }
     Error backend_error() const { return Error{Error::Backend, nh_last_error(ctx_)}; }
     nh_ctx *ctx_;
@@ -245,8 +247,8 @@ class Model {
     std::function<std::string(const uint32_t *, size_t)> detok_;
     DecodingResult last_;
     bool needs_fallback_ = false;
-    bool fallback_ = false;
-    uint64_t seed_ = 0;
+    bool fallback_ = true;
+    uint64_t seed_ = entropy_seed();
     uint32_t slices_ = 0;
     bool detect_ = false;
     std::vector<int32_t> lang_tokens_;
@@ -329,6 +331,7 @@ class Definition {
         assets::GgufFile gg;
         std::vector<std::vector<float>> deq;   // dequantised GGUF tensors (kept alive until the upload below)
         std::vector<TensorView> tv;
+        std::vector<std::pair<size_t, size_t>> bf16_fix;
         if (qext) {
             if (!gg.open(dir + "/model-" + qext + "-q80.gguf", err)) return Error{Error::Backend, err};
             deq.resize(gg.tensors.size());
@@ -339,12 +342,16 @@ class Definition {
         } else {
             if (!st.open(dir + "/model.safetensors", err)) return Error{Error::Backend, err};
             for (const auto &t : st.tensors) {
-                int dt;
-                if (t.dtype == "F16") dt = NH_DTYPE_F16;
-                else if (t.dtype == "F32") dt = NH_DTYPE_F32;
-                else return Error{Error::Backend, "model.safetensors: unsupported dtype " + t.dtype + " for " + t.name};
-                tv.push_back(TensorView{t.name, dt, t.shape, t.data});
+                if (t.dtype == "F16") tv.push_back(TensorView{t.name, NH_DTYPE_F16, t.shape, t.data});
+                else if (t.dtype == "F32") tv.push_back(TensorView{t.name, NH_DTYPE_F32, t.shape, t.data});
+                else if (t.dtype == "BF16") {   // widened on the host (exact); candle casts every dtype to m::DTYPE the same way
+                    deq.emplace_back();
+                    assets::st_to_f32(t, deq.back());
+                    tv.push_back(TensorView{t.name, NH_DTYPE_F32, t.shape, nullptr});
+                    bf16_fix.push_back({tv.size() - 1, deq.size() - 1});
+                } else return Error{Error::Backend, "model.safetensors: unsupported dtype " + t.dtype + " for " + t.name};
             }
+            for (auto &f : bf16_fix) tv[f.first].data = deq[f.second].data();   // deq may have reallocated while growing
         }
         nh_config cfg{cj.num_mel_bins, cj.max_source_positions, cj.d_model, cj.encoder_attention_heads, cj.encoder_layers,
                       cj.vocab_size, cj.max_target_positions, cj.decoder_attention_heads, cj.decoder_layers};

@@ -94,12 +94,17 @@ def test_decode_with_fallback_walks_the_temperatures_and_drops_a_hopeless_slice(
     script = common.transcript_script(tk, n_segments=2, words_per_segment=4)
     cfg, tk, om, model, filt = _pair(common.scripted_overrides(cfg, tk, script, peak_logit=9.5))
     pcm = synth.synth_pcm(0, 160000)
+    model.set_temperature_fallback(False, 0)          # opt out of the reference's loop: the t = 0 result, flagged
     segs0 = model.transcribe(pcm, final_chunk=True)
     last0 = model.last_result()
     assert last0["needed_fallback"] and last0["avg_logprob"] < -1.0 and model.buffered_samples == 0
     om.set_sampling(False, 0)
     ref0, _, _ = om.transcribe(pcm, filt, final_chunk=True)
     assert segs0 == ref0 and len(segs0) == 2
+    # the default (a fresh model): the loop is on, entropy-seeded like the reference -- whatever it draws, nothing is acceptable
+    cfg2, tk2, om2, fresh, _ = _pair(common.scripted_overrides(cfg, tk, script, peak_logit=9.5))
+    assert fresh.transcribe(pcm, final_chunk=True) == [] and fresh.last_result()["avg_logprob"] < -1.0
+    fresh.close(); om2.close()
     model.set_temperature_fallback(True, 11)
     om.set_sampling(True, 11)
     segs1 = model.transcribe(pcm, final_chunk=True)

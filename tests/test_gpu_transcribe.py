@@ -190,3 +190,70 @@ def test_quantized_q8_0_gguf_checkpoint_loads_and_transcribes(tmp_path):
     os.remove(tmp_path / "model-tiny-en-q80.gguf")
     with pytest.raises(host.WhisperError, match="cannot open"):
         d.blocking_try_to_model_from_dir(str(tmp_path))
+
+
+def test_checkpoint_directory_against_independent_loaders_with_a_real_bpe_tokenizer_and_translate(tmp_path):
+    """§8(f)-1/3 with nothing checked HIP-against-HIP: the checkpoint directory holds the fixture tokenizer (byte-level BPE
+    with real merges, multi-byte text, special and timestamp tokens; tests/golden/make_asset_fixtures.py) and a
+    model.safetensors with F16, F32 and BF16 tensors written by the `safetensors` binding.  Expected side: the ORACLE fed
+    the tensors through safetensors' own loader, special ids and text through the `tokenizers` binding (the crates the
+    reference calls: monolingual.rs:237-239, mod.rs:86-90, model.rs:147).  Task = translate, language fixed to <|ja|>:
+    the prompt must be [sot, <|ja|>, <|translate|>] (model.rs:285-289, multilingual.rs:383-386)."""
+    import json
+    import os
+    import shutil
+    torch = pytest.importorskip("torch")
+    tokenizers = pytest.importorskip("tokenizers")
+    from safetensors.torch import load_file, save_file
+    from norma_amd import vocab
+    gold = os.path.join(common.ROOT, "tests", "golden", "assets")
+    shutil.copy(os.path.join(gold, "tokenizer.json"), tmp_path / "tokenizer.json")
+    tok = tokenizers.Tokenizer.from_file(str(tmp_path / "tokenizer.json"))
+    V = tok.get_vocab_size(with_added_tokens=True)
+    tid = tok.token_to_id
+    tk = vocab.SpecialTokens(V, tid("<|endoftext|>"), tid("<|startoftranscript|>"), tid("<|en|>"), tid("<|translate|>"),
+                             tid("<|transcribe|>"), tid("<|nospeech|>"), tid("<|notimestamps|>"), tid("<|0.00|>"), 8)
+    assert tid("<|1.00|>") == tk.one_sec and tk.no_timestamps + 1 == tk.zero_sec
+    cfg = common.make_config("test-d128", vocab_size=V, suppress_tokens=[1, 2, 7, tid("<|startoflm|>"), tid("<|startofprev|>")])
+    s1 = tok.encode("naïve café 日本語のテキスト", add_special_tokens=False).ids
+    s2 = tok.encode(" emoji 🙂 Привет", add_special_tokens=False).ids
+    script = [tk.zero_sec] + s1 + [tk.zero_sec + 40, tk.zero_sec + 42] + s2 + [tk.eot]   # <|t|> text <|t|> <|t|> text eot
+    assert not set(script) & set(cfg.suppress_tokens)
+    over = common.scripted_overrides(cfg, tk, script)
+    tensors = {}
+    for n, a in synth.synth_weights(cfg, 0, over):
+        t = torch.from_numpy(a)
+        if n.endswith("layer_norm.weight") or n.endswith("layer_norm.bias"):
+            tensors[n] = t                                    # F32
+        elif n.endswith(".bias"):
+            tensors[n] = t.to(torch.bfloat16)                 # BF16 (widened exactly by the loader)
+        else:
+            tensors[n] = t.to(torch.float16)                  # F16
+    tensors["proj_out.weight"] = tensors["model.decoder.embed_tokens.weight"].clone()   # in HF files, not read by candle
+    save_file(tensors, str(tmp_path / "model.safetensors"))
+    with open(tmp_path / "config.json", "w") as f:
+        json.dump(cfg.to_dict(), f)
+    # ---- expected: oracle + the reference's crates ----
+    ja, task = tid("<|ja|>"), tk.translate
+    om = common.oracle_module().OracleModel(cfg, tk, ja, task)
+    for n, t in load_file(str(tmp_path / "model.safetensors")).items():
+        if n != "proj_out.weight":
+            om.set_tensor(n, t.to(torch.float32).numpy().astype(np.float16).astype(np.float32) if t.dtype == torch.float16
+                          else t.to(torch.float32).numpy())
+    pcm = synth.synth_pcm(4)
+    filt = assets_io.mel_filters(cfg.num_mel_bins)
+    ref_segs, _, info = om.transcribe(pcm, filt, final_chunk=True)
+    ref_dec = om.decode(om.encoder_forward(common.oracle_module().pcm_to_mel(pcm, filt)))
+    assert ref_dec["tokens"] == [tk.sot, ja, task] + script
+    assert ref_segs == [s1, s2]
+    want_text = "".join(tok.decode(s, skip_special_tokens=True) for s in ref_segs)
+    assert want_text == "naïve café 日本語のテキスト emoji 🙂 Привет"
+    # ---- the HIP host layer from the directory ----
+    d = host.Definition(host.ModelType.Tiny, host.SelectedDevice.Rocm(0))
+    model = d.blocking_try_to_model_from_dir(str(tmp_path), language="<|ja|>", translate=True)
+    segs = model.transcribe(pcm, final_chunk=True)
+    assert segs == ref_segs
+    assert model.last_text() == want_text
+    assert abs(model.last_result()["avg_logprob"] - info["avg_logprob"]) < 5e-3
+    assert model.last_result()["n_tokens"] == len(ref_dec["tokens"])
+    model.close(); om.close()

@@ -161,11 +161,15 @@ def test_argmax_total_cmp_semantics():
 # ---------------------------------------------------------------------------------------------------
 # transformer stack vs transformers' Whisper (secondary cross-check, NOT the reference)
 # ---------------------------------------------------------------------------------------------------
-def test_transformer_stack_matches_hf_whisper_with_tanh_gelu():
+@pytest.mark.parametrize("name,over", [
+    ("test-d128", {}),
+    ("tiny.en", {}),                                                  # BASELINE.json configs 1-2 at full size (EnV1 vocabulary)
+    ("large-v3", {"encoder_layers": 1, "decoder_layers": 1}),        # one layer of the d = 1280 / 20-head / 128-mel / V2 shape
+])
+def test_transformer_stack_matches_hf_whisper_with_tanh_gelu(name, over):
     torch = pytest.importorskip("torch")
     tr = pytest.importorskip("transformers")
-    name = "test-d128"
-    cfg = config.preset(name)
+    cfg = common.make_config(name, **over)
     tk = common.tokens_for(name)
     hc = tr.WhisperConfig(
         vocab_size=cfg.vocab_size, num_mel_bins=cfg.num_mel_bins, encoder_layers=cfg.encoder_layers,
