@@ -91,10 +91,16 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const half_t *__restri
         if (more) load_tile(t + 1);
         const char *tk = smem + cur * 2 * TILE_B, *tv = tk + TILE_B;
         f32x16 s0, s1;
+        {
+            // the first k-step takes a literal zero accumulator (an inline constant of the MFMA, not 32 v_mov per tile)
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            half8 k0 = *reinterpret_cast<const half8 *>(tk + offK0);
+            half8 k1 = *reinterpret_cast<const half8 *>(tk + 4096 + offK0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[0], zero, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[0], zero, 0, 0, 0);
+        }
 #pragma unroll
-        for (int i = 0; i < 16; i++) { s0[i] = 0.f; s1[i] = 0.f; }
-#pragma unroll
-        for (int ks = 0; ks < 4; ks++) {
+        for (int ks = 1; ks < 4; ks++) {
             // chunk 2 ks + hh: (2ks + hh) ^ g == (hh ^ g) ^ (2 ks)  -> byte offset ^ (ks << 5)
             half8 k0 = *reinterpret_cast<const half8 *>(tk + (offK0 ^ (ks << 5)));
             half8 k1 = *reinterpret_cast<const half8 *>(tk + 4096 + (offK0 ^ (ks << 5)));
@@ -119,13 +125,21 @@ __global__ __launch_bounds__(256, 2) void enc_attn_kernel(const half_t *__restri
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
         const float mb = m_new * c_exp;
-        float ps = 0.f;
+        // exponent arguments and the row sum two values per instruction (v_pk_fma_f32 / v_pk_add_f32): this kernel is bound
+        // by VALU + transcendental issue, not by the matrix pipe (32 v_exp_f32 per tile are unavoidable, the rest is not)
+        f32x2 ps2 = {0.f, 0.f};
+        const f32x2 c2 = {c_exp, c_exp}, nmb2 = {-mb, -mb};
 #pragma unroll
-        for (int i = 0; i < 16; i++) {
-            s0[i] = __builtin_amdgcn_exp2f(s0[i] * c_exp - mb);
-            s1[i] = __builtin_amdgcn_exp2f(s1[i] * c_exp - mb);
-            ps += s0[i] + s1[i];
+        for (int i = 0; i < 16; i += 2) {
+            f32x2 a = {s0[i], s0[i + 1]}, b = {s1[i], s1[i + 1]};
+            a = __builtin_elementwise_fma(a, c2, nmb2);
+            b = __builtin_elementwise_fma(b, c2, nmb2);
+            a[0] = __builtin_amdgcn_exp2f(a[0]); a[1] = __builtin_amdgcn_exp2f(a[1]);
+            b[0] = __builtin_amdgcn_exp2f(b[0]); b[1] = __builtin_amdgcn_exp2f(b[1]);
+            ps2 += a; ps2 += b;
+            s0[i] = a[0]; s0[i + 1] = a[1]; s1[i] = b[0]; s1[i + 1] = b[1];
         }
+        const float ps = ps2[0] + ps2[1];
         l_run = l_run * alpha + ps;
         m_run = m_new;
         // the running maximum settles after the first tiles: when no query of the wave moved it, alpha is exactly 1 and the

@@ -8,6 +8,7 @@ typedef _Float16 half_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 half8;
 typedef __attribute__((ext_vector_type(4))) _Float16 half4;
 typedef __attribute__((ext_vector_type(2))) _Float16 half2v;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
