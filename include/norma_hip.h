@@ -107,6 +107,27 @@ int nh_missing_tensors(const nh_ctx *ctx);
  * n_samples[b] <= 480000 valid samples (the rest is treated as absent, exactly as pcm_to_mel pads
  * with zeros).  Computes the log-mel of every clip on device. */
 int nh_logmel(nh_ctx *ctx, const float *pcm, const int32_t *n_samples, int64_t stride, int batch);
+/* The sample types norma's `DType` trait admits (src/dtype.rs:37-45): the capture side hands the transcriber samples of the
+ * device's native type and converts them with dasp_sample (`Sample::to_sample::<T::Data>`, src/lib.rs:180,207) to the model's
+ * Data type -- f32 for Whisper (model.rs:49).  nh_logmel_samples takes the native samples (host memory) and does that
+ * conversion on the GPU, so a 16-bit microphone stream crosses PCIe at 2 bytes per sample.  Conversions are dasp_sample's:
+ *   i8/i16/i32/i64 -> f32:  (s as f32) / 2^(bits-1)          u8/u16/u32/u64 -> f32: the same after subtracting 2^(bits-1)
+ *   f64 -> f32: s as f32 (round to nearest even)             f32: unchanged
+ * (integer -> f32 conversions round to nearest even, as Rust's `as` does). */
+#define NH_SAMPLE_F32 0
+#define NH_SAMPLE_F64 1
+#define NH_SAMPLE_I8 2
+#define NH_SAMPLE_I16 3
+#define NH_SAMPLE_I32 4
+#define NH_SAMPLE_I64 5
+#define NH_SAMPLE_U8 6
+#define NH_SAMPLE_U16 7
+#define NH_SAMPLE_U32 8
+#define NH_SAMPLE_U64 9
+/* Bytes per sample of an NH_SAMPLE_* type (0: unknown). */
+int nh_sample_size(int sample_dtype);
+/* Like nh_logmel, with `pcm` holding samples of type `sample_dtype` (host memory, `stride` SAMPLES between clips). */
+int nh_logmel_samples(nh_ctx *ctx, const void *pcm, int sample_dtype, const int32_t *n_samples, int64_t stride, int batch);
 /* Same, but pcm is a DEVICE pointer (already resident in HBM; no copy). */
 int nh_logmel_device(nh_ctx *ctx, const float *pcm_dev, const int32_t *n_samples, int64_t stride, int batch);
 /* Encoder forward over the mel of the last nh_logmel call (flush = true semantics: the cross

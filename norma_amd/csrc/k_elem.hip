@@ -99,3 +99,38 @@ void launch_embed(const int32_t *tokens, int tok_stride, const half_t *E, const 
                   int Tn, int t0, const int32_t *pos_ptr, int d, hipStream_t st) {
     hipLaunchKernelGGL(embed_kernel, dim3(B * Tn), dim3(256), 0, st, tokens, tok_stride, E, P, x, Tn, t0, pos_ptr, d);
 }
+
+// dasp_sample's conversions to f32 (the capture side of the reference converts every native sample type to Model::Data with
+// Sample::to_sample, src/lib.rs:180,207; the admissible types are src/dtype.rs:37-45).  Signed: s / 2^(bits - 1); unsigned:
+// (s - 2^(bits - 1)) / 2^(bits - 1), the subtraction in integers; f64: round to nearest.  Integer -> float conversions
+// round to nearest even (v_cvt_f32_i32, and the compiler's i64 sequence), like Rust's `as f32`; the divisions are by
+// powers of two, i.e. exact.
+template <typename T> __device__ __forceinline__ float sample_to_f32(T v);
+template <> __device__ __forceinline__ float sample_to_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ float sample_to_f32<double>(double v) { return (float)v; }
+template <> __device__ __forceinline__ float sample_to_f32<int8_t>(int8_t v) { return (float)v * (1.0f / 128.0f); }
+template <> __device__ __forceinline__ float sample_to_f32<int16_t>(int16_t v) { return (float)v * (1.0f / 32768.0f); }
+template <> __device__ __forceinline__ float sample_to_f32<int32_t>(int32_t v) { return (float)v * (1.0f / 2147483648.0f); }
+template <> __device__ __forceinline__ float sample_to_f32<int64_t>(int64_t v) { return (float)v * (1.0f / 9223372036854775808.0f); }
+template <> __device__ __forceinline__ float sample_to_f32<uint8_t>(uint8_t v) { return (float)((int)v - 128) * (1.0f / 128.0f); }
+template <> __device__ __forceinline__ float sample_to_f32<uint16_t>(uint16_t v) { return (float)((int)v - 32768) * (1.0f / 32768.0f); }
+template <> __device__ __forceinline__ float sample_to_f32<uint32_t>(uint32_t v) { return (float)(int32_t)(v ^ 0x80000000u) * (1.0f / 2147483648.0f); }
+template <> __device__ __forceinline__ float sample_to_f32<uint64_t>(uint64_t v) { return (float)(int64_t)(v ^ 0x8000000000000000ull) * (1.0f / 9223372036854775808.0f); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void convert_samples_kernel(const T *__restrict__ src, float *__restrict__ dst, long count) {
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < count; i += (long)gridDim.x * 256L) dst[i] = sample_to_f32<T>(src[i]);
+}
+
+void launch_convert_samples(const void *src, float *dst, long count, int dtype, hipStream_t st) {
+    if (count <= 0) return;
+    long nb = (count + 255) / 256; if (nb > 4096) nb = 4096;
+    const dim3 grid((unsigned)nb), block(256);
+#define CONV(T) hipLaunchKernelGGL(convert_samples_kernel<T>, grid, block, 0, st, reinterpret_cast<const T *>(src), dst, count)
+    switch (dtype) {
+        case 0: CONV(float); break;     case 1: CONV(double); break;
+        case 2: CONV(int8_t); break;    case 3: CONV(int16_t); break;  case 4: CONV(int32_t); break;  case 5: CONV(int64_t); break;
+        case 6: CONV(uint8_t); break;   case 7: CONV(uint16_t); break; case 8: CONV(uint32_t); break; default: CONV(uint64_t); break;
+    }
+#undef CONV
+}

@@ -57,6 +57,7 @@ struct nh_ctx {
     int32_t *mel_grp = nullptr;
     bool have_filters = false;
     float *pcm = nullptr;
+    void *raw = nullptr; size_t raw_bytes = 0;   // native-sample staging of nh_logmel_samples
     int32_t *nsamp = nullptr;
     float *mel32 = nullptr;
     unsigned *chunk_max = nullptr;
@@ -548,6 +549,43 @@ extern "C" int nh_logmel(nh_ctx *ctx, const float *pcm, const int32_t *n_samples
         HIPCHK(hipMemcpyAsync(ctx->pcm + (size_t)b * NH_N_SAMPLES, pcm + (size_t)b * stride, sizeof(float) * n_samples[b],
                               hipMemcpyHostToDevice, ctx->st));
     }
+    return run_logmel(ctx, ctx->pcm, n_samples, NH_N_SAMPLES, batch);
+}
+
+extern "C" int nh_sample_size(int dt) {
+    switch (dt) {
+        case NH_SAMPLE_F32: case NH_SAMPLE_I32: case NH_SAMPLE_U32: return 4;
+        case NH_SAMPLE_F64: case NH_SAMPLE_I64: case NH_SAMPLE_U64: return 8;
+        case NH_SAMPLE_I16: case NH_SAMPLE_U16: return 2;
+        case NH_SAMPLE_I8: case NH_SAMPLE_U8: return 1;
+        default: return 0;
+    }
+}
+
+// src/dtype.rs + dasp_sample's Sample::to_sample::<f32> (src/lib.rs:180,207), on the device: the native samples cross PCIe
+// as they are and become Model::Data (f32) in HBM
+extern "C" int nh_logmel_samples(nh_ctx *ctx, const void *pcm, int sample_dtype, const int32_t *n_samples, int64_t stride, int batch) {
+    if (!ctx || !pcm || !n_samples) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_logmel_samples: bad arguments") : NH_ERR_INVALID;
+    const size_t es = (size_t)nh_sample_size(sample_dtype);
+    if (!es) return ctx->fail(NH_ERR_INVALID, "nh_logmel_samples: unknown sample type " + std::to_string(sample_dtype));
+    if (sample_dtype == NH_SAMPLE_F32) return nh_logmel(ctx, reinterpret_cast<const float *>(pcm), n_samples, stride, batch);
+    hipSetDevice(ctx->dev);
+    if (batch < 1 || batch > ctx->B) return ctx->fail(NH_ERR_INVALID, "batch must be in [1, max_batch]");
+    const size_t need = (size_t)ctx->B * NH_N_SAMPLES * es;
+    if (ctx->raw_bytes < need) {   // staging for the native samples, sized for the widest type seen so far
+        void *p = nullptr;
+        if (hipMalloc(&p, need) != hipSuccess) return ctx->fail(NH_ERR_NOMEM, "hipMalloc(native sample staging)");
+        ctx->allocs.push_back(p);
+        ctx->raw = p; ctx->raw_bytes = need;
+    }
+    for (int b = 0; b < batch; b++) {
+        if (n_samples[b] < 1 || n_samples[b] > NH_N_SAMPLES) return ctx->fail(NH_ERR_INVALID, "clip length must be in [1, 480000] samples");
+        char *dst = reinterpret_cast<char *>(ctx->raw) + (size_t)b * NH_N_SAMPLES * es;
+        HIPCHK(hipMemcpyAsync(dst, reinterpret_cast<const char *>(pcm) + (size_t)b * (size_t)stride * es, (size_t)n_samples[b] * es,
+                              hipMemcpyHostToDevice, ctx->st));
+        launch_convert_samples(dst, ctx->pcm + (size_t)b * NH_N_SAMPLES, n_samples[b], sample_dtype, ctx->st);
+    }
+    HIPCHK(hipGetLastError());
     return run_logmel(ctx, ctx->pcm, n_samples, NH_N_SAMPLES, batch);
 }
 

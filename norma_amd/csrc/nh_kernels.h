@@ -143,6 +143,10 @@ void launch_layernorm(const float *x, const float *w, const float *b, half_t *y,
 void launch_embed(const int32_t *tokens, int tok_stride, const half_t *E, const half_t *P, float *x, int B,
                   int Tn, int t0, const int32_t *pos_ptr, int d, hipStream_t st);
 
+// ---- sample conversion (src/dtype.rs / dasp_sample): native capture samples -> f32 PCM -------------------------------
+// src: `count` samples of NH_SAMPLE_* type `dtype` (device memory); dst: f32
+void launch_convert_samples(const void *src, float *dst, long count, int dtype, hipStream_t st);
+
 // ---- log-mel -------------------------------------------------------------------------------------------
 struct MelTables {      // device pointers, built once on the host with libm (bit-identical twiddles)
     const float *hann;      // [400]

@@ -121,6 +121,19 @@ static const char *const LANGUAGE_CODES[99] = {
     "gl", "mr", "pa", "si", "km", "sn", "yo", "so", "af", "oc", "ka", "be", "tg", "sd", "gu", "am", "yi", "lo", "uz", "fo",
     "ht", "ps", "tk", "nn", "mt", "sa", "lb", "my", "bo", "tl", "mg", "as", "tt", "haw", "ln", "ha", "ba", "jw", "su"};
 
+// crate::dtype::DType (src/dtype.rs:10-45): the sample types a capture stream may deliver.  `valid` marks the four that are
+// candle DTypes in the reference (u8, u32, f32, f64: "These are valid DTypes"); the others "can (will) be converted".  Here
+// every one of them maps to an NH_SAMPLE_* code of the C ABI, whose nh_logmel_samples does dasp_sample's conversion to
+// Model::Data (f32) on the GPU.
+template <typename T> struct DType;
+#define NORMA_DTYPE(T, CODE, VALID) template <> struct DType<T> { static constexpr int sample = CODE; static constexpr bool valid = VALID; }
+NORMA_DTYPE(uint8_t, NH_SAMPLE_U8, true);   NORMA_DTYPE(uint32_t, NH_SAMPLE_U32, true);
+NORMA_DTYPE(float, NH_SAMPLE_F32, true);    NORMA_DTYPE(double, NH_SAMPLE_F64, true);
+NORMA_DTYPE(int8_t, NH_SAMPLE_I8, false);   NORMA_DTYPE(int16_t, NH_SAMPLE_I16, false);
+NORMA_DTYPE(int32_t, NH_SAMPLE_I32, false); NORMA_DTYPE(int64_t, NH_SAMPLE_I64, false);
+NORMA_DTYPE(uint16_t, NH_SAMPLE_U16, false); NORMA_DTYPE(uint64_t, NH_SAMPLE_U64, false);
+#undef NORMA_DTYPE
+
 enum class Task { Transcribe, Translate };  // multilingual.rs:19-25
 
 struct DecodingResult {  // model.rs:494-499

@@ -21,6 +21,10 @@ N_SAMPLES = 480000
 N_FRAMES = 3000
 NH_DTYPE_F32, NH_DTYPE_F16 = 0, 1
 NH_OPT_DECODE_GRAPHS, NH_OPT_FUSE_DECODE_LAYERNORM = 0, 1
+# NH_SAMPLE_* of include/norma_hip.h (the types of src/dtype.rs)
+SAMPLE_DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int8): 2, np.dtype(np.int16): 3,
+                 np.dtype(np.int32): 4, np.dtype(np.int64): 5, np.dtype(np.uint8): 6, np.dtype(np.uint16): 7,
+                 np.dtype(np.uint32): 8, np.dtype(np.uint64): 9}
 
 
 class HipError(RuntimeError):
@@ -85,6 +89,8 @@ def load_library() -> C.CDLL:
     L.nh_missing_tensors.argtypes = [vp]
     L.nh_logmel.argtypes = [vp, fp, ip, C.c_int64, C.c_int]
     L.nh_logmel_device.argtypes = [vp, vp, ip, C.c_int64, C.c_int]
+    L.nh_logmel_samples.argtypes = [vp, vp, C.c_int, ip, C.c_int64, C.c_int]
+    L.nh_sample_size.argtypes = [C.c_int]
     L.nh_encode.argtypes = [vp]
     L.nh_decode_greedy.argtypes = [vp, ip, C.POINTER(NhDecodeResult), C.c_int]
     L.nh_decode_sampled.argtypes = [vp, ip, C.POINTER(NhDecodeResult), C.c_int, C.c_float, C.c_uint64, C.c_uint32, C.c_uint32]
@@ -199,6 +205,15 @@ class HipWhisper:
         B, stride = pcm.shape
         ns = np.full(B, stride, dtype=np.int32) if n_samples is None else np.asarray(n_samples, dtype=np.int32)
         self._chk(self.L.nh_logmel(self._h, _fp(pcm), _ip(ns), stride, B))
+        self.batch = B
+
+    def logmel_samples(self, pcm: np.ndarray, n_samples: Optional[Sequence[int]] = None):
+        """pcm: contiguous [batch][stride] array of a native capture type (src/dtype.rs: u8 .. f64); converted to f32 on the
+        GPU with dasp_sample's formulas (nh_logmel_samples)."""
+        assert pcm.ndim == 2 and pcm.flags.c_contiguous and pcm.dtype in SAMPLE_DTYPES
+        B, stride = pcm.shape
+        ns = np.full(B, stride, dtype=np.int32) if n_samples is None else np.asarray(n_samples, dtype=np.int32)
+        self._chk(self.L.nh_logmel_samples(self._h, pcm.ctypes.data_as(C.c_void_p), SAMPLE_DTYPES[pcm.dtype], _ip(ns), stride, B))
         self.batch = B
 
     def logmel_device(self, pcm_dev_ptr: int, n_samples: Sequence[int], stride: int):
