@@ -1018,9 +1018,10 @@ __global__ __launch_bounds__(256) void logit_step_kernel(const float *__restrict
         __hip_atomic_store(pp + 5, bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(reinterpret_cast<int *>(pp) + 6, ai, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(reinterpret_cast<int *>(pp) + 7, bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // write-through (sc1) payload, drained, then the ticket: no L2 write-back fence needed
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned t = __hip_atomic_fetch_add(tickets + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the ticket is an acq_rel read-modify-write at agent scope: the relaxed payload stores above happen-before the
+        // combine of whichever workgroup draws the last ticket (HIP / HSA memory model; r01 ordered them with a bare
+        // s_waitcnt, which the hardware honours but the model does not promise)
+        unsigned t = __hip_atomic_fetch_add(tickets + b, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
         sh_last = (t == LSPLIT - 1);
     }
     __syncthreads();

@@ -22,6 +22,30 @@ def partition(n_chunks: int, world: int) -> List[Tuple[int, int]]:
     return out
 
 
+def partition_balanced(costs: Sequence[float], world: int) -> List[List[int]]:
+    """Chunk indices per rank when the chunks are NOT equally expensive (clips of different length; a job whose first
+    pass measured decode lengths): longest-processing-time greedy -- chunks by decreasing cost, each to the least loaded
+    rank, ties to the lower rank; indices inside a rank stay in chunk order.  With equal costs this degenerates to a
+    round-robin deal whose counts equal partition()'s (20 over 8 -> 3,3,3,3,2,2,2,2)."""
+    load = [0.0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in sorted(range(len(costs)), key=lambda i: (-costs[i], i)):
+        k = min(range(world), key=lambda r: (load[r], len(out[r]), r))
+        out[k].append(i)
+        load[k] += costs[i]
+    return [sorted(v) for v in out]
+
+
+def scatter_order(assignment: Sequence[Sequence[int]]) -> List[int]:
+    """Flattened (rank-major) chunk order of an assignment: results gathered rank by rank are put back in chunk order with
+    `[gathered[pos] for pos in inverse]`, inverse[chunk] = position of that chunk in the flattened list."""
+    flat = [i for v in assignment for i in v]
+    inv = [0] * len(flat)
+    for pos, i in enumerate(flat):
+        inv[i] = pos
+    return inv
+
+
 def pack_results(results: Sequence[dict], ctx_len: int, slots: int) -> np.ndarray:
     """results -> int32 [slots][ctx_len + 6]: tokens | n | no_speech_exit | avg_logprob (2 x i32) |
     no_speech_prob (2 x i32), doubles bit-cast so one integer tensor carries everything."""

@@ -84,3 +84,21 @@ def test_world_size_2_gloo_sharding_equals_single_process():
     for a, b in zip(got, ref):
         assert a["tokens"] == b["tokens"]
         assert a["avg_logprob"] == b["avg_logprob"] and a["no_speech_prob"] == b["no_speech_prob"]
+
+
+def test_balanced_partition_for_unequal_chunks():
+    from norma_amd import shard
+    # equal costs: same counts as the contiguous split of BASELINE config 4
+    eq = shard.partition_balanced([1.0] * 20, 8)
+    assert sorted(len(v) for v in eq) == sorted(c for _, c in shard.partition(20, 8))
+    assert sorted(i for v in eq for i in v) == list(range(20))
+    # unequal: one 30 s clip next to many short ones -- the long ones are spread, the maximum load is near the mean
+    costs = [30, 30, 30, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 2, 2, 2, 2, 2]
+    a = shard.partition_balanced(costs, 4)
+    loads = [sum(costs[i] for i in v) for v in a]
+    assert max(loads) <= 1.15 * sum(costs) / 4 and sorted(i for v in a for i in v) == list(range(20))
+    contiguous = [sum(costs[s:s + c]) for s, c in shard.partition(20, 4)]
+    assert max(loads) < max(contiguous)
+    inv = shard.scatter_order(a)
+    flat = [i for v in a for i in v]
+    assert [flat[inv[i]] for i in range(20)] == list(range(20))
