@@ -1,39 +1,23 @@
-// k_attn_enc.hip -- encoder self-attention, flash style (gfx950 MFMA + LDS tiles).
-//
-// Replaces candle's MultiHeadAttention::qkv_attention for the AudioEncoder blocks (two batched
-// matmuls + softmax_last_dim materialising [B,H,1500,1500]; reached from Type::encoder_forward,
-// src/models/whisper/model.rs:455-464).  Scores never leave the chip: per 64-key tile
-// S^T = K Q^T (v_mfma_f32_32x32x16_f16), online softmax in registers (fp32, one query per lane,
-// max/sum finished with one cross-half shuffle), O^T += V^T P^T.
-//
-// Layout tricks (CDNA4 fragment maps, cdna_hip_programming.md 3):
-//  * "swapped" QK^T puts a query on the lane and the tile's keys in the 16 accumulator registers,
-//    so softmax is lane-local and the P registers are directly the B operand of the PV MFMA.
-//  * the accumulator's k order is row = 16s + 8(j>>2) + 4h + (j&3); storing K rows in LDS with
-//    bits 2 and 3 of the row index swapped makes that order "8 consecutive keys per (s,h)", so the
-//    V^T fragment is one aligned 16-byte LDS read.  V^T ([b][h][64][1536]) is written directly by
-//    the QKV GEMM epilogue (k_gemm.hip), never transposed here.
-//  * K and V^T tiles are [64 rows][128 B] images with chunk' = chunk ^ ((row >> 1) & 7):
-//    conflict-free ds_read_b128 for both fragment shapes.
-// The q/k pre-scaling by dh^-1/4 each is folded into one exact *1/8 inside the
-// exponent.  1500 keys are not a multiple of 64: the last tile masks keys >= S; V^T pad is zero.
-#include "nh_kernels.h"
-
+// attn_trace: where does a 64-key tile of enc_attn_kernel spend its ~3100 cycles?  A copy of the kernel body with clock64
+// stamps (shader clock) around the stages of one wave, run at 1, 2 and 3 workgroups per CU (LDS padding), distil-large-v3
+// shapes (B = 32, H = 20, S = 1500).  Prints average cycles per stage over tiles 4..19 of one wave.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include "../norma_amd/csrc/nh_kernels.h"
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 #define KT 64              // keys per tile
 #define QW 32              // queries per wave
-#ifndef ENC_ATTN_WAVES
-#define ENC_ATTN_WAVES 8   // waves per workgroup
-#endif
-#define QB (QW * ENC_ATTN_WAVES)   // queries per workgroup
-#define NTHR (64 * ENC_ATTN_WAVES)
-#define NSLOT (NTHR >= 512 ? 1 : 512 / NTHR)   // 16-byte staging slots per thread per tile (a tile is 512 slots; threads >= 512 stage nothing)
+#define QB 128             // queries per workgroup
 #define TILE_B 8192        // bytes per K or V^T tile
 
 __device__ __forceinline__ int swap23(int x) { return (x & ~12) | ((x & 4) << 1) | ((x & 8) >> 1); }
 
-__global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(const half_t *__restrict__ q, const half_t *__restrict__ k,
+__global__ __launch_bounds__(256, 2) void enc_attn_trace(const half_t *__restrict__ q, const half_t *__restrict__ k,
                                                          long ld, const half_t *__restrict__ vt,
-                                                         half_t *__restrict__ out, long ldo, int S, int H) {
+                                                         half_t *__restrict__ out, long ldo, int S, int H, unsigned long long *stamps) {
+    unsigned long long T[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0;
+    const bool rec = blockIdx.x == 3 && blockIdx.y == 5 && blockIdx.z == 1 && threadIdx.x == 0;
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_B];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -49,34 +33,31 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(c
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) qf[ks] = *reinterpret_cast<const half8 *>(qp + 16 * ks);
     }
-    // staging: slot s = tid + NTHR i (i < NSLOT): LDS row = s >> 3, chunk' = s & 7
-    const half_t *kg[NSLOT]; const half_t *vg[NSLOT];
-    int krow_off[NSLOT];
+    // staging: slot s = tid + 256 i (i = 0,1): LDS row = s >> 3, chunk' = s & 7
+    const half_t *kg[2]; const half_t *vg[2];
+    int krow_off[2];
 #pragma unroll
-    for (int i = 0; i < NSLOT; i++) {
-        int row = (tid >> 3) + (NTHR / 8) * i;
+    for (int i = 0; i < 2; i++) {
+        int row = (tid >> 3) + 32 * i;
         int c = (tid & 7) ^ ((row >> 1) & 7);
         krow_off[i] = swap23(row);  // LDS row `row` holds key key0 + swap23(row)
         kg[i] = k + (long)b * S * ld + h * NH_DH + c * 8;
         vg[i] = vt + ((long)(b * H + h) * NH_DH + row) * NH_SP + c * 8;
     }
-    u32x4 rk[NSLOT], rv[NSLOT];
-    const bool stager = NTHR <= 512 || tid < 512;
+    u32x4 rk[2], rv[2];
     auto load_tile = [&](int t) {
-        if (!stager) return;
 #pragma unroll
-        for (int i = 0; i < NSLOT; i++) {
+        for (int i = 0; i < 2; i++) {
             int key = t * KT + krow_off[i]; if (key >= S) key = S - 1;
             rk[i] = *reinterpret_cast<const u32x4 *>(kg[i] + (long)key * ld);
             rv[i] = *reinterpret_cast<const u32x4 *>(vg[i] + t * KT);
         }
     };
     auto store_tile = [&](int buf) {
-        if (!stager) return;
         u32x4 *lk = reinterpret_cast<u32x4 *>(smem + buf * 2 * TILE_B);
         u32x4 *lv = reinterpret_cast<u32x4 *>(smem + buf * 2 * TILE_B + TILE_B);
 #pragma unroll
-        for (int i = 0; i < NSLOT; i++) { lk[tid + NTHR * i] = rk[i]; lv[tid + NTHR * i] = rv[i]; }
+        for (int i = 0; i < 2; i++) { lk[tid + 256 * i] = rk[i]; lv[tid + 256 * i] = rv[i]; }
     };
     load_tile(0);
     store_tile(0);
@@ -96,6 +77,8 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(c
     int cur = 0;
     for (int t = 0; t < nT; t++) {
         const bool more = (t + 1 < nT);
+        const bool tr = t >= 4 && t < 20;
+        unsigned long long k0_ = clock64();
         if (more) load_tile(t + 1);
         const char *tk = smem + cur * 2 * TILE_B, *tv = tk + TILE_B;
         f32x16 s0, s1;
@@ -115,6 +98,8 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(c
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[ks], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[ks], s1, 0, 0, 0);
         }
+        asm volatile("s_nop 0" ::"v"(s0[0]), "v"(s1[0]));
+        unsigned long long k1_ = clock64();   // QK MFMAs done (their results were just read)
         if (t * KT + KT > S) {  // last, partial tile: mask keys >= S
 #pragma unroll
             for (int i = 0; i < 16; i++) {
@@ -130,6 +115,7 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(c
 #pragma unroll
         for (int i = 0; i < 16; i++) mx = fmaxf(mx, s1[i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
+        unsigned long long k2_ = clock64();   // max reduce + shuffle
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
         const float mb = m_new * c_exp;
@@ -148,6 +134,8 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(c
             s0[i] = a[0]; s0[i + 1] = a[1]; s1[i] = b[0]; s1[i + 1] = b[1];
         }
         const float ps = ps2[0] + ps2[1];
+        asm volatile("s_nop 0" ::"v"(ps));
+        unsigned long long k3_ = clock64();   // exponentials + row sum
         l_run = l_run * alpha + ps;
         m_run = m_new;
         // the running maximum settles after the first tiles: when no query of the wave moved it, alpha is exactly 1 and the
@@ -175,10 +163,17 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(c
             v = *reinterpret_cast<const half8 *>(tv + (offV0 ^ (6 << 4)));          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, p11, o0, 0, 0, 0);
             v = *reinterpret_cast<const half8 *>(tv + 4096 + (offV0 ^ (6 << 4)));   o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, p11, o1, 0, 0, 0);
         }
+        asm volatile("s_nop 0" ::"v"(o0[0]), "v"(o1[0]));
+        unsigned long long k4_ = clock64();   // cvt + V reads + PV MFMAs done
         if (more) store_tile(cur ^ 1);
+        unsigned long long k5_ = clock64();   // wait for the next tile's global loads + LDS store
         __syncthreads();
+        unsigned long long k6_ = clock64();   // barrier
+        if (tr) { T[0] += k1_ - k0_; T[1] += k2_ - k1_; T[2] += k3_ - k2_; T[3] += k4_ - k3_; T[4] += k5_ - k4_; T[5] += k6_ - k5_; T[6] += k6_ - k0_; T[7] += 1; }
+        (void)tprev;
         cur ^= 1;
     }
+    if (rec) for (int i = 0; i < 8; i++) stamps[i] = T[i];
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + r;
@@ -196,8 +191,26 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(c
     }
 }
 
-void launch_enc_attention(const half_t *q, const half_t *k, long ld, const half_t *vt, half_t *out, long ldo,
-                          int B, int S, int H, hipStream_t st) {
-    dim3 grid((S + QB - 1) / QB, H, B);
-    hipLaunchKernelGGL(enc_attn_kernel, grid, dim3(NTHR), 0, st, q, k, ld, vt, out, ldo, S, H);
+
+int main() {
+    const int B = 32, H = 20, S = 1500, d = 1280;
+    half_t *q, *k, *vt, *out; unsigned long long *st;
+    CK(hipMalloc(&q, (size_t)B * S * d * 2)); CK(hipMalloc(&k, (size_t)B * S * d * 2)); CK(hipMalloc(&vt, (size_t)B * d * NH_SP * 2));
+    CK(hipMalloc(&out, (size_t)B * S * d * 2)); CK(hipMalloc(&st, 64));
+    CK(hipMemset(q, 0x11, (size_t)B * S * d * 2)); CK(hipMemset(k, 0x12, (size_t)B * S * d * 2)); CK(hipMemset(vt, 0x13, (size_t)B * d * NH_SP * 2));
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    const char *names[7] = {"loads issue + K reads + QK MFMAs", "max + shuffle", "exp + sum", "cvt + V reads + PV MFMAs", "vmcnt wait + LDS store", "barrier", "whole tile"};
+    for (int pad : {60000, 40000, 0}) {
+        dim3 grid((S + QB - 1) / QB, H, B);
+        for (int rep = 0; rep < 2; rep++) {
+            hipEventRecord(a, 0);
+            hipLaunchKernelGGL(enc_attn_trace, grid, dim3(256), pad, 0, q, k, (long)d, vt, out, (long)d, S, H, st);
+            hipEventRecord(b, 0); CK(hipEventSynchronize(b));
+        }
+        float ms; hipEventElapsedTime(&ms, a, b);
+        unsigned long long h[8]; CK(hipMemcpy(h, st, 64, hipMemcpyDeviceToHost));
+        printf("LDS pad %5d (%s workgroups per CU): kernel %.1f us\n", pad, pad == 0 ? "3" : pad == 40000 ? "2" : "1", ms * 1e3);
+        for (int i = 0; i < 7; i++) printf("    %-34s %8.0f cycles\n", names[i], (double)h[i] / (double)h[7]);
+    }
+    return 0;
 }
