@@ -102,12 +102,16 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
     const int fr = lane & 15, fq = lane >> 4;
     // tile base row of this wave
     const int n0 = KSPLIT == 1 ? (blockIdx.x * NW + w) * 16 * NT : blockIdx.x * 16;
+    // gridDim.y > 1: workgroup y handles activation rows rb .. rb + 16 NCB only (every CU must fetch the activation rows it
+    // multiplies, and that fetch -- 35-47 KB/us per CU -- is what these kernels wait for: with few weight tiles it pays to
+    // spread the ROWS over more CUs too; per-row arithmetic is unchanged, so results are)
+    const int rb = blockIdx.y * 16 * NCB;
     // epilogue operands (bias, residual) of the element this thread will own: fetched now, so their latency
     // hides under the weight stream instead of extending the dependent chain of this latency-bound kernel
     f32x4 pre[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
     const bool can_pre = KSPLIT != 1 && (p.N & 3) == 0;
     if (can_pre) {
-        const int er = tid >> 2, en = n0 + 4 * (tid & 3);
+        const int er = rb + (tid >> 2), en = n0 + 4 * (tid & 3);
         if (tid < 64 * NCB && er < p.R && en < p.N) {
             if (p.bias) pre[0] = *reinterpret_cast<const f32x4 *>(p.bias + en);
             if (p.epi == SK_RESID_F32) pre[1] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.out[0]) + (long)er * p.ldo + en);
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
     const half_t *xp[NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) {
-        int r = 16 * cb + fr; if (r >= p.R) r = p.R - 1;
+        int r = rb + 16 * cb + fr; if (r >= p.R) r = p.R - 1;
         xp[cb] = p.x + (long)r * p.ldx + kbeg + 8 * fq;
     }
     f32x4 acc[NT][NCB];
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
         for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int cb = 0; cb < NCB; cb++) {
-                int r = 16 * cb + fr;
+                int r = rb + 16 * cb + fr;
                 if (r < p.R) skinny_store(p, acc[t][cb], r, n0 + 16 * t + 4 * fq);
             }
         return;
@@ -158,11 +162,11 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
     __syncthreads();
     // thread t owns row r = t / 4 and the 4 consecutive features n0 + 4 (t % 4) + i:
     // D[n = 4 fq + i][r = fr] lives in lane 16 fq + fr of column block r / 16
-    const int r = tid >> 2, nq = tid & 3;
+    const int rl = tid >> 2, nq = tid & 3, r = rb + rl;
     const bool owner = (tid < 64 * NCB) && (r < p.R);
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (owner) {
-        const int src_lane = 16 * nq + (r & 15), cb = r >> 4;
+        const int src_lane = 16 * nq + (rl & 15), cb = rl >> 4;
         v = red[0][cb][src_lane];
 #pragma unroll
         for (int ww = 1; ww < KSPLIT; ww++) v += red[ww][cb][src_lane];
@@ -178,38 +182,50 @@ __global__ __launch_bounds__(KSPLIT == 1 ? 128 : 64 * KSPLIT) void skinny_gemm_k
 // residual stream; the row statistics meet through LDS (two passes over the register-resident values, the "sliced"
 // summation tree of nh_kernels.h), gamma/beta are staged in LDS once per workgroup.
 // ---------------------------------------------------------------------------------------------------
-template <int NCB, int STEPS>
+template <int NCB, int STEPS, int NT>
 __global__ __launch_bounds__(256) void skinny_ln_kernel(SkinnyParams p) {
     constexpr int K = 128 * STEPS;
-    __shared__ f32x4 red[4][NCB][64];
+    __shared__ f32x4 red[4][NT][NCB][64];
     __shared__ float part[2][4][NCB][16];
     __shared__ __attribute__((aligned(16))) float gb[2][K];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 16;
+    // A workgroup owns NT consecutive 16-row weight tiles and the activation rows rb .. rb + 16 NCB (gridDim.y row blocks).
+    // What it waits for is its own fetch (35-47 KB/us per CU): NT x 41 KB of weights + 16 NCB rows x K f32 of activations,
+    // so the launcher shapes (NT, NCB, grid) to keep that sum small while every CU has work.
+    const int tiles = (p.N + 15) >> 4, tile0 = blockIdx.x * NT;
+    const int rb = blockIdx.y * 16 * NCB;
     const int kbeg = w * 32 * STEPS;
     // weights first: the only HBM stream of the kernel
-    int wrow = n0 + fr; if (wrow >= p.N) wrow = p.N - 1;
-    const half_t *wp = p.Wt ? p.Wt + ((long)blockIdx.x * (K >> 5) + (kbeg >> 5)) * 512 + lane * 8 : p.W + (long)wrow * K + kbeg + 8 * fq;
     const int wstep = p.Wt ? 512 : 32;
-    half8 a[STEPS];
+    half8 a[NT][STEPS];
 #pragma unroll
-    for (int s = 0; s < STEPS; s++) a[s] = *reinterpret_cast<const half8 *>(wp + wstep * s);
-    // epilogue operands of the element this thread will own (see skinny_gemm_kernel)
-    f32x4 pre[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    for (int t = 0; t < NT; t++) {
+        const int tile = tile0 + t < tiles ? tile0 + t : tiles - 1;   // a tail workgroup re-reads the last tile; its stores are skipped
+        int wrow = tile * 16 + fr; if (wrow >= p.N) wrow = p.N - 1;
+        const half_t *wp = p.Wt ? p.Wt + ((long)tile * (K >> 5) + (kbeg >> 5)) * 512 + lane * 8 : p.W + (long)wrow * K + kbeg + 8 * fq;
+#pragma unroll
+        for (int s = 0; s < STEPS; s++) a[t][s] = *reinterpret_cast<const half8 *>(wp + wstep * s);
+    }
+    // epilogue operands of the elements this thread will own (see skinny_gemm_kernel)
+    f32x4 pre[NT][2];
     const bool can_pre = (p.N & 3) == 0;
-    if (can_pre) {
-        const int er = tid >> 2, en = n0 + 4 * (tid & 3);
-        if (tid < 64 * NCB && er < p.R && en < p.N) {
-            if (p.bias) pre[0] = *reinterpret_cast<const f32x4 *>(p.bias + en);
-            if (p.epi == SK_RESID_F32) pre[1] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.out[0]) + (long)er * p.ldo + en);
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        pre[t][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; pre[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (can_pre) {
+            const int er = rb + (tid >> 2), en = (tile0 + t) * 16 + 4 * (tid & 3);
+            if (tid < 64 * NCB && er < p.R && en < p.N) {
+                if (p.bias) pre[t][0] = *reinterpret_cast<const f32x4 *>(p.bias + en);
+                if (p.epi == SK_RESID_F32) pre[t][1] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.out[0]) + (long)er * p.ldo + en);
+            }
         }
     }
     // the rows, f32
     f32x4 xv[NCB][STEPS][2];
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) {
-        int r = 16 * cb + fr; if (r >= p.R) r = p.R - 1;
+        int r = rb + 16 * cb + fr; if (r >= p.R) r = p.R - 1;
         const float *xr = p.ln_x + (long)r * K + kbeg + 8 * fq;
 #pragma unroll
         for (int s = 0; s < STEPS; s++) {
@@ -241,11 +257,12 @@ __global__ __launch_bounds__(256) void skinny_ln_kernel(SkinnyParams p) {
         if (fq == 0) part[1][w][cb][fr] = s2;
     }
     __syncthreads();
-    f32x4 acc[NCB];
+    f32x4 acc[NT][NCB];
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) {
         inv[cb] = ln_inv((part[1][0][cb][fr] + part[1][1][cb][fr]) + (part[1][2][cb][fr] + part[1][3][cb][fr]), p.ln_rk);
-        acc[cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NT; t++) acc[t][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
     for (int s = 0; s < STEPS; s++) {
@@ -258,19 +275,26 @@ __global__ __launch_bounds__(256) void skinny_ln_kernel(SkinnyParams p) {
             const f32x4 o1 = ln_apply(xv[cb][s][1], mean[cb], inv[cb], g1, b1);
             const half8 b = {(half_t)o0[0], (half_t)o0[1], (half_t)o0[2], (half_t)o0[3],
                              (half_t)o1[0], (half_t)o1[1], (half_t)o1[2], (half_t)o1[3]};
-            acc[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s], b, acc[cb], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < NT; t++) acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[t][s], b, acc[t][cb], 0, 0, 0);
         }
     }
 #pragma unroll
-    for (int cb = 0; cb < NCB; cb++) red[w][cb][lane] = acc[cb];
-    __syncthreads();
-    const int r = tid >> 2, nq = tid & 3;
-    if (tid < 64 * NCB && r < p.R) {
-        const int src_lane = 16 * nq + (r & 15), cb = r >> 4;
-        f32x4 v = red[0][cb][src_lane];  // same association as skinny_gemm_kernel: the two forms give identical bits
+    for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int ww = 1; ww < 4; ww++) v += red[ww][cb][src_lane];
-        skinny_store(p, v, r, n0 + 4 * nq, can_pre, pre[0], pre[1]);
+        for (int cb = 0; cb < NCB; cb++) red[w][t][cb][lane] = acc[t][cb];
+    __syncthreads();
+    const int rl = tid >> 2, nq = tid & 3, r = rb + rl;
+    if (tid < 64 * NCB && r < p.R) {
+        const int src_lane = 16 * nq + (rl & 15), cb = rl >> 4;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            if (tile0 + t >= tiles) break;
+            f32x4 v = red[0][t][cb][src_lane];  // same association as skinny_gemm_kernel: the two forms give identical bits
+#pragma unroll
+            for (int ww = 1; ww < 4; ww++) v += red[ww][t][cb][src_lane];
+            skinny_store(p, v, r, (tile0 + t) * 16 + 4 * nq, can_pre, pre[t][0], pre[t][1]);
+        }
     }
 }
 
@@ -485,18 +509,27 @@ bool skinny_ln_supported(int R, int N, int K) {
     return ln_steps_ok(K);
 }
 
+template <int NCB, int NT>
+static void launch_skinny_ln_grid(const SkinnyParams &p, dim3 grid, hipStream_t st) {
+    const dim3 block(256);
+    switch (p.K / 128) {
+        case 1: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 1, NT>), grid, block, 0, st, p); break;
+        case 2: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 2, NT>), grid, block, 0, st, p); break;
+        case 3: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 3, NT>), grid, block, 0, st, p); break;
+        case 4: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 4, NT>), grid, block, 0, st, p); break;
+        case 6: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 6, NT>), grid, block, 0, st, p); break;
+        case 8: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 8, NT>), grid, block, 0, st, p); break;
+        default: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 10, NT>), grid, block, 0, st, p); break;
+    }
+}
 template <int NCB>
 static void launch_skinny_ln(const SkinnyParams &p, hipStream_t st) {
-    const dim3 grid((p.N + 15) / 16), block(256);
-    switch (p.K / 128) {
-        case 1: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 1>), grid, block, 0, st, p); break;
-        case 2: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 2>), grid, block, 0, st, p); break;
-        case 3: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 3>), grid, block, 0, st, p); break;
-        case 4: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 4>), grid, block, 0, st, p); break;
-        case 6: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 6>), grid, block, 0, st, p); break;
-        case 8: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 8>), grid, block, 0, st, p); break;
-        default: hipLaunchKernelGGL((skinny_ln_kernel<NCB, 10>), grid, block, 0, st, p); break;
-    }
+    const int tiles = (p.N + 15) / 16;
+    // per-CU fetch = NT x (16 rows of W) + (16 NCB rows of x, f32): few tiles -> one tile x one 16-row block per workgroup;
+    // many tiles -> two tiles x one 16-row block (as many workgroups as tiles, a fifth fewer bytes each than 1 tile x 32 rows)
+    if (NCB > 1 && tiles <= 160) launch_skinny_ln_grid<1, 1>(p, dim3(tiles, NCB), st);
+    else if (NCB == 2) launch_skinny_ln_grid<1, 2>(p, dim3((tiles + 1) / 2, 2), st);
+    else launch_skinny_ln_grid<NCB, 1>(p, dim3(tiles), st);
 }
 
 template <int NCB>
@@ -532,10 +565,22 @@ static void launch_skinny_ncb(const SkinnyParams &p, hipStream_t st) {
     // same ~11 us); 16 waves of one workgroup meet in LDS.
     auto fits = [&](int nw) { return p.K % (nw * 32) == 0; };
     // (the slicing must not depend on the batch: one summation order for every NCB = bit-exact batch invariance)
-    if (p.K >= 2560 && fits(16)) hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 16, 1>), dim3(tiles), dim3(1024), 0, st, p);
-    else if (p.K >= 2560 && fits(8)) hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 8, 1>), dim3(tiles), dim3(512), 0, st, p);
-    else if (fits(4)) hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 4, 1>), dim3(tiles), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 2, 1>), dim3(tiles), dim3(128), 0, st, p);
+    // Few weight tiles (N <= 2560): one workgroup per (tile, 16-row block of the activations) -- the single-block
+    // instantiation on a tiles x NCB grid -- so that a CU fetches 16 rows of activations instead of all of them
+    // (skinny_gemm_kernel, rb).  Same per-row arithmetic as the NCB-block form.
+    constexpr int RBN = NCB;   // row blocks when split
+    const bool split_rows = NCB > 1 && tiles * NCB <= 640 && tiles <= 160;
+    const dim3 grid = split_rows ? dim3(tiles, RBN) : dim3(tiles);
+#define SKG(KS, THR)                                                                                               \
+    do {                                                                                                            \
+        if (split_rows) hipLaunchKernelGGL((skinny_gemm_kernel<1, KS, 1>), grid, dim3(THR), 0, st, p);             \
+        else hipLaunchKernelGGL((skinny_gemm_kernel<NCB, KS, 1>), grid, dim3(THR), 0, st, p);                      \
+    } while (0)
+    if (p.K >= 2560 && fits(16)) SKG(16, 1024);
+    else if (p.K >= 2560 && fits(8)) SKG(8, 512);
+    else if (fits(4)) SKG(4, 256);
+    else SKG(2, 128);
+#undef SKG
 }
 
 void launch_skinny(const SkinnyParams &p_in, hipStream_t st) {
