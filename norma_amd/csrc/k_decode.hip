@@ -504,9 +504,8 @@ static bool logits_lds_ok(int R, int N, int K) {
     return (N + 15) / 16 >= 2048 && R <= 32 && (size_t)(K >> 5) * 16 * ((R + 15) / 16) * 64 <= 96 * 1024;
 }
 bool skinny_ln_supported(int R, int N, int K) {
-    if (R > 32) return false;
-    if ((N + 15) / 16 >= 2048) return logits_lds_ok(R, N, K) && K <= 128 * LN_MAX_STEPS && K % 128 == 0;
-    return ln_steps_ok(K);
+    if ((N + 15) / 16 >= 2048) return R <= 32 && logits_lds_ok(R, N, K) && K <= 128 * LN_MAX_STEPS && K % 128 == 0;
+    return R <= 64 && ln_steps_ok(K);   // one 16-row block per workgroup: any number of row blocks
 }
 
 template <int NCB, int NT>
@@ -528,15 +527,15 @@ static void launch_skinny_ln(const SkinnyParams &p, hipStream_t st) {
     // per-CU fetch = NT x (16 rows of W) + (16 NCB rows of x, f32): few tiles -> one tile x one 16-row block per workgroup;
     // many tiles -> two tiles x one 16-row block (as many workgroups as tiles, a fifth fewer bytes each than 1 tile x 32 rows)
     if (NCB > 1 && tiles <= 160) launch_skinny_ln_grid<1, 1>(p, dim3(tiles, NCB), st);
-    else if (NCB == 2) launch_skinny_ln_grid<1, 2>(p, dim3((tiles + 1) / 2, 2), st);
-    else launch_skinny_ln_grid<NCB, 1>(p, dim3(tiles), st);
+    else if (NCB > 1) launch_skinny_ln_grid<1, 2>(p, dim3((tiles + 1) / 2, NCB), st);
+    else launch_skinny_ln_grid<1, 1>(p, dim3(tiles), st);
 }
 
 template <int NCB>
 static void launch_skinny_ncb(const SkinnyParams &p, hipStream_t st) {
     const int tiles = (p.N + 15) / 16;
-    if (p.ln_x && tiles < 2048) {  // the caller checked skinny_ln_supported: NCB <= 2
-        if (NCB == 1) launch_skinny_ln<1>(p, st); else launch_skinny_ln<2>(p, st);
+    if (p.ln_x && tiles < 2048) {  // the caller checked skinny_ln_supported
+        launch_skinny_ln<NCB>(p, st);
         return;
     }
     if (tiles >= 2048) {  // the tied-embedding logits: plenty of tiles, stream full rows
