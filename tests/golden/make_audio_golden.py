@@ -32,7 +32,9 @@ MIN_MARGIN = 0.03
 MAX_ITERATIONS = 30
 # 55 distinct pairs, each met twice (110 audio-decided steps + 22 fixed ones): the votes of ALL pairs are added at every
 # step, so their number, not the transcript length, is what dilutes the steering
-MODELS = {"tiny.en": dict(n_pairs=55, repeats=2, pos_rms=4.0, vote=1.0), "distil-large-v3": dict(n_pairs=55, repeats=2, pos_rms=4.0, vote=1.0)}
+MODELS = {"tiny.en": dict(n_pairs=55, repeats=2, pos_rms=4.0, vote=1.0), "distil-large-v3": dict(n_pairs=55, repeats=2, pos_rms=4.0, vote=1.0),
+          # 32 random decoder layers dilute the steering (see tests/test_gpu_configs.py): a stronger positional table
+          "large-v3": dict(n_pairs=55, repeats=2, pos_rms=8.0, vote=1.0)}
 
 
 def build(name, n_pairs, repeats, pos_rms, vote):

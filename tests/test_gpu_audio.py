@@ -128,3 +128,10 @@ def test_sequences_that_finish_at_different_steps_match_the_oracle():
         r1 = h1.decode_greedy()[0]
         assert r1["tokens"] == got[i]["tokens"] and r1["avg_logprob"] == got[i]["avg_logprob"]
     hm.close(); h1.close(); om.close()
+
+
+@pytest.mark.skipif("large-v3" not in GOLD, reason="golden not generated for large-v3")
+def test_large_v3_audio_dependent_transcripts_match_the_oracle_token_for_token():
+    """BASELINE config 5's model at full depth (32 + 32 layers): four clips, audio-decided tokens, against the golden (oracle)
+    transcripts; one clip re-derived with the oracle on the box."""
+    _check("large-v3", oracle_clips=[1])
