@@ -5,7 +5,9 @@
  * pointers and sizes only; no C++ or torch types.  Every function returns an int status
  * (NH_OK == 0) and never throws or aborts; nh_last_error() gives the message for the last
  * failure on that context.  A context is owned by one host thread (the reference's `Model` is
- * `Send`, not `Sync`: src/models/mod.rs:24, src/lib.rs:377,462-464); use one context per GPU.
+ * `Send`, not `Sync`: src/models/mod.rs:24, src/lib.rs:377,462-464).  One process may hold any number of contexts, on one
+ * device or several, each driven by its own thread; they share nothing mutable.  Several contexts on ONE device are how the
+ * latency-bound decode of one batch is overlapped with the encoder of the next (bench.py keeps three batches in flight).
  *
  * All citations are relative to the reference repository MikeIvanichev/norma @ 2024_10_08.
  *
