@@ -567,7 +567,7 @@ void launch_gemm(const GemmParams &p, hipStream_t st) {
     const bool seg_ok = (p.epi != EPI_F16 && p.epi != EPI_GELU_F16) || (p.seg_n % G2_BN == 0);
     if (p.N % G2_BN == 0 && p.K % 128 == 0 && seg_ok && p.M >= G2_BM) {
         const int nwg = (p.N / G2_BN) * ((p.M + G2_BM - 1) / G2_BM);
-        int cus = device_cu_count();
+        int cus = p.cus > 0 ? p.cus : device_cu_count();  // persistent grid: one workgroup per CU the stream can reach
         cus -= cus % 8;  // the tile order assumes workgroups b and b + gridDim.x sit on the same XCD
         const dim3 grid(nwg < cus ? nwg : cus), block(512);
         switch (p.epi) {  // one instantiation per epilogue: a single accumulator-init / store path each (register pressure)

@@ -39,6 +39,7 @@ struct GemmParams {
                                                 // instead of [m][seg_n]: the decoder streams cross K/V per (clip, head)
     int S, H;                                   // rows per clip / heads (V^T and conv2 epilogues)
     const float *pos;                           // conv2: positional embedding [S][N]
+    int cus;                                    // workgroups of the persistent grid; 0 = one per CU (tools/cumask runs it on CU-masked streams)
 };
 void launch_gemm(const GemmParams &p, hipStream_t st);
 void launch_gemm_128(const GemmParams &p, hipStream_t st);  // always the 128 x 128 kernel
