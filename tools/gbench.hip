@@ -1,4 +1,5 @@
 // gbench: the encoder GEMM kernels on the distil-large-v3 b32 shapes, random fp16 data, TFLOP/s per shape.
+// GEMM_128=1 times the 128 x 128 kernel (two workgroups per CU) on the same shapes: 0.48-0.79 PFLOP/s against 0.63-1.07.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -14,6 +15,8 @@ __global__ void fill_rand(half_t *p, size_t n, unsigned seed) {
 }
 int main(int argc, char **argv) {
     hipStream_t st; CK(hipStreamCreate(&st));
+    const bool k128 = getenv("GEMM_128") && atoi(getenv("GEMM_128"));  // time the 128 x 128 kernel (two workgroups per CU) instead
+    auto launch = [&](const GemmParams &p) { if (k128) launch_gemm_128(p, st); else launch_gemm(p, st); };
     const int M = argc > 1 ? atoi(argv[1]) : 48000;
     struct Shape { int N, K, epi; const char *name; };
     // gbench M N K epi: one custom shape (N <= 5120, K <= 5120) instead of the encoder's six
@@ -41,11 +44,11 @@ int main(int argc, char **argv) {
         p.seg_n = (s.N == 3840 || s.N == 2560) ? 1280 : s.N; p.ldo = (s.epi == EPI_RESID_F32 || s.epi == EPI_CONV2_F32) ? 1280 : p.seg_n;
         p.o_rpb = M; p.vt_seg = s.N == 3840 ? 2 : -1; p.S = 1500; p.H = 20; p.pos = pos;
         if (s.N == 3840) { p.out[0] = O0; p.out[1] = O1; }
-        for (int i = 0; i < 3; i++) launch_gemm(p, st);
+        for (int i = 0; i < 3; i++) launch(p);
         CK(hipStreamSynchronize(st));
         const int reps = 10;
         hipEventRecord(a, st);
-        for (int i = 0; i < reps; i++) launch_gemm(p, st);
+        for (int i = 0; i < reps; i++) launch(p);
         hipEventRecord(b, st); CK(hipEventSynchronize(b));
         float ms; hipEventElapsedTime(&ms, a, b);
         double tf = 2.0 * M * s.N * s.K * reps / (ms * 1e-3) / 1e12;
