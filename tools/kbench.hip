@@ -30,7 +30,15 @@ static double bench(const char *name, int reps, std::function<void()> f, double 
 }
 int main(int argc, char **argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 32, d = 1280, V = 51866, VP = (V + 63) & ~63, C = 448, S = 1500, H = 20;
-    CK(hipStreamCreate(&st));
+    // KBENCH_CUS=n: run everything on a stream confined to the first n CUs (n / 8 per XCD) -- how the decode kernels scale
+    // down; the stream is not destroyed (hipStreamDestroy of a masked stream hangs on ROCm 7.2)
+    if (getenv("KBENCH_CUS") && atoi(getenv("KBENCH_CUS")) > 0) {
+        const int n = atoi(getenv("KBENCH_CUS"));
+        uint32_t mask[8] = {0};
+        for (int i = 0; i < n && i < 256; i++) mask[i >> 5] |= 1u << (i & 31);
+        CK(hipExtStreamCreateWithCUMask(&st, 8, mask));
+        printf("stream confined to %d CUs\n", n);
+    } else CK(hipStreamCreate(&st));
     const size_t ARENA = (size_t)300 << 20;  // halfs (600 MB): larger than the 256 MB Infinity Cache
     half_t *arena = dmalloc<half_t>(ARENA, 0x11), *w_e = arena;
     size_t rot = 0;
