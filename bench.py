@@ -58,6 +58,8 @@ def parse_args(argv=None):
                     help="batches in flight per GPU (workload b32): each pipeline is its own context + host thread; "
                          "encoders are serialised by a host lock, the latency-bound decode of one batch runs beside the "
                          "MFMA-bound encoder of the next.  1 = one batch at a time")
+    ap.add_argument("--no-graphs", action="store_true", help="A/B: launch every decode-step kernel eagerly (NH_OPT_DECODE_GRAPHS = 0)")
+    ap.add_argument("--no-ln-fusion", action="store_true", help="A/B: stand-alone decoder LayerNorm kernels (NH_OPT_FUSE_DECODE_LAYERNORM = 0)")
     ap.add_argument("--no-single-extra", action="store_true", help="skip the one-batch-at-a-time measurement in `extra`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-new-tokens", type=int, default=96)
@@ -222,6 +224,10 @@ def worker(args):
         h = hip.HipWhisper(cfg, device=local_rank, max_batch=max(B, 1))
         h.set_mel_filters(assets_io.mel_filters(cfg.num_mel_bins))
         h.set_tokens(tk, -1 if multilingual else tk.en, tk.transcribe)
+        if args.no_graphs:
+            h.set_option(hip.NH_OPT_DECODE_GRAPHS, 0)
+        if args.no_ln_fusion:
+            h.set_option(hip.NH_OPT_FUSE_DECODE_LAYERNORM, 0)
         hms.append(h)
     hm = hms[0]
     want_cpu = (not args.no_cpu_baseline) and headline and world == 1 and rank == 0

@@ -199,10 +199,14 @@ int nh_get_timings(nh_ctx *ctx, nh_timings *out);
 /* 1: bracket every encoder GEMM launch with a pair of HIP event records on its stream (no synchronisation; bench roofline). */
 int nh_set_profile_gemm(nh_ctx *ctx, int enable);
 
-/* A/B switches for the bit-exactness screens in tests/ (the defaults are the product configuration; nothing here
- * changes results, only how the decode step is launched). */
+/* A/B switches for the bit-exactness screens in tests/ (the defaults are the product configuration; options 0 and 1 change
+ * only how the decode step is launched, never its results). */
 #define NH_OPT_DECODE_GRAPHS 0          /* 1 (default): replay the captured decode step; 0: launch every kernel eagerly */
 #define NH_OPT_FUSE_DECODE_LAYERNORM 1  /* 1 (default): LayerNorm inside the consuming GEMV; 0: stand-alone LayerNorm kernel */
+/* Parity view, the one option that DOES change results: n > 0 runs only the first n decoder blocks of TextDecoder::forward
+ * (model.rs:466-476) before the final LayerNorm, so a test can compare the hidden state against an oracle built with n decoder
+ * layers and see how the fp16 error grows with depth; 0 (default) = all of them. */
+#define NH_OPT_DECODER_LAYER_LIMIT 2
 int nh_set_option(nh_ctx *ctx, int option, int value);
 
 #ifdef __cplusplus

@@ -79,6 +79,7 @@ struct nh_ctx {
     int graph_key[5] = {-1, -1, -1, -1, -1};
     int token_gen = 0;  // bumped by nh_set_tokens; part of the graph key
     bool opt_graphs = true, opt_fuse_ln = true;  // nh_set_option
+    int dec_layer_limit = 0;    // parity view (NH_OPT_DECODER_LAYER_LIMIT): run only the first n decoder blocks; 0 = all
     std::vector<int32_t> seq_lang;  // per-sequence language tokens (LanguageState::Detect), empty = tk.lang for all
     int32_t *d_lang_tokens = nullptr, *d_lang_out = nullptr;
     float *d_lang_probs = nullptr;
@@ -735,7 +736,9 @@ static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr,
     const int32_t *done = skip_done ? ctx->ds.done : nullptr;
     const int d = ctx->c.d_model, B = ctx->cur_batch, H = ctx->c.decoder_attention_heads, C = ctx->c.max_target_positions;
     launch_embed(ctx->ds.tokens, C, ctx->tok_emb, ctx->dec_pos, ctx->dx, B, 1, pos, pos_ptr, d, ctx->sd);
+    int nl = 0;
     for (auto &L : ctx->dec) {
+        if (ctx->dec_layer_limit > 0 && nl++ >= ctx->dec_layer_limit) break;  // depth profile of the parity tests
         ln_skinny(ctx, L.ln1, L.qkv, B, 3 * d, d, SK_QKV, ctx->dq, L.sk, L.sv, d, pos, C, pos_ptr);
         launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos_ptr, ctx->sd, 1, done);  // head-major cache
         skinny(ctx, ctx->datt, d, L.o, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
@@ -1067,6 +1070,10 @@ extern "C" int nh_set_option(nh_ctx *ctx, int option, int value) {
     if (!ctx) return NH_ERR_INVALID;
     if (option == NH_OPT_DECODE_GRAPHS) ctx->opt_graphs = value != 0;
     else if (option == NH_OPT_FUSE_DECODE_LAYERNORM) { ctx->opt_fuse_ln = value != 0; drop_graphs(ctx); }
+    else if (option == NH_OPT_DECODER_LAYER_LIMIT) {
+        if (value < 0 || value > ctx->c.decoder_layers) return ctx->fail(NH_ERR_INVALID, "nh_set_option: layer limit outside [0, decoder_layers]");
+        ctx->dec_layer_limit = value; drop_graphs(ctx);
+    }
     else return ctx->fail(NH_ERR_INVALID, "nh_set_option: unknown option " + std::to_string(option));
     return NH_OK;
 }

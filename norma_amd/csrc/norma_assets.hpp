@@ -170,7 +170,11 @@ struct StTensor {
 inline size_t st_elem_size(const std::string &dt) { return dt == "F32" ? 4 : (dt == "F16" || dt == "BF16") ? 2 : 0; }
 // widen one tensor to f32 (F32 copy, F16 / BF16 exact)
 inline bool st_to_f32(const StTensor &t, std::vector<float> &out) {
+    // dtype and size first: the shape of a tensor of any OTHER dtype has not been checked against its byte range as
+    // n * elem_size (SafeTensors::open only bounds it), so nothing may be sized from it
+    const size_t es = st_elem_size(t.dtype);
     const size_t n = t.n_elem();
+    if (!es || n > (size_t)-1 / es || n * es != t.bytes) return false;
     out.resize(n);
     if (t.dtype == "F32") memcpy(out.data(), t.data, n * 4);
     else if (t.dtype == "F16") { const _Float16 *h = reinterpret_cast<const _Float16 *>(t.data); for (size_t i = 0; i < n; i++) out[i] = (float)h[i]; }
@@ -212,6 +216,9 @@ class SafeTensors {
             if (e < b || e > avail) { err = "safetensors: offsets out of range for " + kv.first; return false; }
             const size_t es = st_elem_size(t.dtype);
             if (es && (n > (size_t)-1 / es || e - b != n * es)) { err = "safetensors: " + kv.first + " declares " + std::to_string(n) + " " + t.dtype + " elements over " + std::to_string(e - b) + " bytes"; return false; }
+            // a dtype this reader does not widen (I64, U8, F8_E4M3 ... -- never read by Whisper): listed, never converted; its
+            // shape must still be plausible for its byte range (the smallest safetensors element is one byte)
+            if (!es && n > e - b) { err = "safetensors: " + kv.first + " declares " + std::to_string(n) + " " + t.dtype + " elements over " + std::to_string(e - b) + " bytes"; return false; }
             t.data = base + b; t.bytes = e - b;
             tensors.push_back(std::move(t));
         }

@@ -18,6 +18,14 @@ static void put_err(char *err, int n, const std::string &s) {
     err[n - 1] = 0;
 }
 
+// No exception may cross the C boundary (norma_hip.h: "never throws or aborts"): the readers below size buffers from what an
+// untrusted file declares, so std::bad_alloc / std::length_error are reachable.  Every entry point that parses a file, or
+// allocates in proportion to its arguments, runs inside this guard and reports the failure through its error channel.
+#define NM_TRY try {
+#define NM_CATCH(on_fail)                                                             \
+    } catch (const std::exception &ex_) { const std::string what_ = ex_.what(); on_fail; } \
+    catch (...) { const std::string what_ = "unknown exception"; on_fail; }
+
 extern "C" {
 
 nm_definition *nm_definition_new(int model_type, int device_kind, size_t ordinal) {
@@ -41,21 +49,25 @@ void nm_tensors_free(nm_tensors *t) { delete t; }
 nm_model *nm_definition_blocking_try_to_model(const nm_definition *d, const nh_config *cfg, const nh_tokens *tk,
                                               const int32_t *suppress, int n_suppress, const float *mel_filters,
                                               int n_mel, const nm_tensors *tensors, char *err, int err_len) {
+    NM_TRY
     Model *m = nullptr;
     std::vector<int32_t> sup(suppress, suppress + (n_suppress > 0 ? n_suppress : 0));
     Error e = d->def.blocking_try_to_model(*cfg, *tk, sup, mel_filters, n_mel, tensors->v, &m);
     if (e) { put_err(err, err_len, e.message); return nullptr; }
     return new nm_model{m, std::string()};
+    NM_CATCH({ put_err(err, err_len, "blocking_try_to_model: " + what_); return nullptr; })
 }
 
 nm_model *nm_definition_blocking_try_to_model_from_dir(const nm_definition *d, const char *dir, const float *mel_filters,
                                                        int n_mel, const char *language, int translate, char *err,
                                                        int err_len) {
+    NM_TRY
     Model *m = nullptr;
     const bool detect = language == nullptr || language[0] == 0;  // multilingual::Definition: infer the language
     Error e = d->def.blocking_try_to_model_from_dir(dir, mel_filters, n_mel, &m, detect ? "" : language, translate != 0, detect);
     if (e) { put_err(err, err_len, e.message); return nullptr; }
     return new nm_model{m, std::string()};
+    NM_CATCH({ put_err(err, err_len, "blocking_try_to_model_from_dir: " + what_); return nullptr; })
 }
 
 void nm_model_enable_language_detection(nm_model *m, const int32_t *lang_tokens, int n) {
@@ -73,6 +85,7 @@ void nm_model_free(nm_model *m) { if (m) { delete m->m; delete m; } }
 
 int nm_model_transcribe(nm_model *m, const float *data, size_t n, int final_chunk, int32_t *out_tokens, int cap,
                         int *n_out, size_t *buffered, char *err, int err_len) {
+    NM_TRY
     std::vector<float> v(data, data + n);
     std::vector<Segment> segs;
     m->last_text.clear();
@@ -87,9 +100,11 @@ int nm_model_transcribe(nm_model *m, const float *data, size_t n, int final_chun
     }
     if (n_out) *n_out = w;
     return 0;
+    NM_CATCH({ put_err(err, err_len, "transcribe: " + what_); return 1; })
 }
 
 int nm_gguf_list(const char *path, char *buf, int cap) {
+    NM_TRY
     norma::assets::GgufFile g; std::string err;
     if (!path || !g.open(path, err)) { put_err(buf, cap, err.empty() ? "nm_gguf_list: no path" : err); return -1; }
     std::string out;
@@ -103,6 +118,7 @@ int nm_gguf_list(const char *path, char *buf, int cap) {
     }
     put_err(buf, cap, out);
     return (int)g.tensors.size();
+    NM_CATCH({ put_err(buf, cap, "nm_gguf_list: " + what_); return -1; })
 }
 
 // Language::iter() order (languages.rs:7-107): code i of the table the host layer resolves "<|code|>" tokens from
@@ -112,21 +128,27 @@ const char *nm_language_code(int i) { return i >= 0 && i < 99 ? LANGUAGE_CODES[i
 // `safetensors` Python bindings of the crates the reference uses (model.rs:147, mod.rs:86-90, monolingual.rs:237-239)
 struct nm_tokenizer { norma::assets::TokenizerJson t; };
 nm_tokenizer *nm_tokenizer_open(const char *path, char *err, int err_len) {
-    auto *t = new nm_tokenizer();
+    nm_tokenizer *t = nullptr;
+    NM_TRY
+    t = new nm_tokenizer();
     std::string e;
     if (!path || !t->t.load(path, e)) { put_err(err, err_len, e.empty() ? "nm_tokenizer_open: no path" : e); delete t; return nullptr; }
     return t;
+    NM_CATCH({ put_err(err, err_len, "nm_tokenizer_open: " + what_); delete t; return nullptr; })
 }
 void nm_tokenizer_free(nm_tokenizer *t) { delete t; }
 int nm_tokenizer_token_to_id(const nm_tokenizer *t, const char *token) { return t && token ? t->t.token_to_id(token) : -1; }
 int nm_tokenizer_decode(const nm_tokenizer *t, const uint32_t *ids, size_t n, int skip_special_tokens, char *buf, int cap) {
     if (!t) return -1;
+    NM_TRY
     const std::string s = t->t.decode(ids, n, skip_special_tokens != 0);
     if (buf && cap > 0) { const size_t m = s.size() < (size_t)cap - 1 ? s.size() : (size_t)cap - 1; memcpy(buf, s.data(), m); buf[m] = 0; }
     return (int)s.size();
+    NM_CATCH({ (void)what_; return -1; })
 }
 
 int nm_safetensors_list(const char *path, char *buf, int cap) {
+    NM_TRY
     norma::assets::SafeTensors st; std::string err;
     if (!path || !st.open(path, err)) { put_err(buf, cap, err.empty() ? "nm_safetensors_list: no path" : err); return -1; }
     std::string out;
@@ -142,6 +164,7 @@ int nm_safetensors_list(const char *path, char *buf, int cap) {
     }
     put_err(buf, cap, out);
     return (int)st.tensors.size();
+    NM_CATCH({ put_err(buf, cap, "nm_safetensors_list: " + what_); return -1; })
 }
 
 void nm_model_set_temperature_fallback(nm_model *m, int enable, uint64_t seed) {

@@ -14,13 +14,16 @@ import numpy as np
 from .config import Config
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnorma_hip.so")
+# NORMA_HIP_LIB selects another BUILD of the same HIP library (libnorma_hip_strict.so: -DNH_STRICT_MEMORY_MODEL); there is no
+# other implementation to select
+LIB_PATH = os.environ.get("NORMA_HIP_LIB") or os.path.join(_HERE, "libnorma_hip.so")
+STRICT_LIB_PATH = os.path.join(_HERE, "libnorma_hip_strict.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "norma_hip.h")
 
 N_SAMPLES = 480000
 N_FRAMES = 3000
 NH_DTYPE_F32, NH_DTYPE_F16 = 0, 1
-NH_OPT_DECODE_GRAPHS, NH_OPT_FUSE_DECODE_LAYERNORM = 0, 1
+NH_OPT_DECODE_GRAPHS, NH_OPT_FUSE_DECODE_LAYERNORM, NH_OPT_DECODER_LAYER_LIMIT = 0, 1, 2
 # NH_SAMPLE_* of include/norma_hip.h (the types of src/dtype.rs)
 SAMPLE_DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int8): 2, np.dtype(np.int16): 3,
                  np.dtype(np.int32): 4, np.dtype(np.int64): 5, np.dtype(np.uint8): 6, np.dtype(np.uint16): 7,

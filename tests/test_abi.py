@@ -19,6 +19,15 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"declared in norma_hip.h but not exported: {missing}"
 
 
+def test_strict_memory_model_build_exists_and_exports_the_same_abi():
+    """The -DNH_STRICT_MEMORY_MODEL variant of k_decode.hip (portable release / acquire spelling of the logit step's
+    cross-workgroup hand-off) is compiled by every build so that it cannot rot; tests/test_gpu_kernels.py runs it."""
+    assert os.path.exists(hip.STRICT_LIB_PATH), "make -C norma_amd/csrc builds libnorma_hip_strict.so"
+    L = C.CDLL(hip.STRICT_LIB_PATH)
+    missing = [s for s in hip.declared_symbols() if not hasattr(L, s)]
+    assert not missing, missing
+
+
 def test_no_oracle_or_cpu_fallback_in_product_sources():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     bad = []

@@ -97,10 +97,17 @@ def test_malformed_checkpoints_are_rejected_not_read_past_the_mapping(L, tmp_pat
         "shape product overflows": _st_file(tmp_path, "e.st", {"w": {"dtype": "F32", "shape": [2 ** 40, 2 ** 40], "data_offsets": [0, 24]}}, b"\0" * 24),
         "end before begin": _st_file(tmp_path, "f.st", {"w": {"dtype": "F32", "shape": [1], "data_offsets": [8, 4]}}, b"\0" * 24),
         "truncated json": _st_file(tmp_path, "g.st", ok, b"", header_len=10),
+        # a dtype the reader does not widen used to skip the size cross-check, and st_to_f32 sized a vector from
+        # the declared shape before looking at the dtype (bad_alloc through an extern "C" function = abort)
+        "unknown dtype, huge shape": _st_file(tmp_path, "h.st", {"w": {"dtype": "I64", "shape": [2 ** 40, 1024], "data_offsets": [0, 24]}}, b"\0" * 24),
     }
     for what, path in cases.items():
         assert L.nm_safetensors_list(path, buf, len(buf)) == -1, what
         assert buf.value, what
+    # an unknown dtype with a plausible shape is listed (sums 0: never converted), not rejected and not sized from
+    listed = _st_file(tmp_path, "i.st", {"w": {"dtype": "I64", "shape": [3], "data_offsets": [0, 24]}}, b"\1" * 24)
+    assert L.nm_safetensors_list(listed, buf, len(buf)) == 1
+    assert buf.value.decode().split()[:3] == ["w", "I64", "3"] and float(buf.value.decode().split()[3]) == 0.0
     # GGUF: element count / offset arithmetic
     import gguf_writer
     good = tmp_path / "ok.gguf"

@@ -112,6 +112,7 @@ def test_sequences_that_finish_at_different_steps_match_the_oracle():
     hm = common.build_hip(cfg, tk, overrides=over, max_batch=len(clips))
     hm.logmel(clips); hm.encode()
     got = hm.decode_greedy()
+    compared = []
     for i, (g, r) in enumerate(zip(got, refs)):
         n = len(r["tokens"]) - 3
         margins = (r["steps"][:n, 0] - r["steps"][:n, 1]) / r["steps"][:n, 0]
@@ -119,6 +120,9 @@ def test_sequences_that_finish_at_different_steps_match_the_oracle():
             continue                                        # a near-tie in the oracle itself: not a fair identity check
         assert g["tokens"] == r["tokens"], (i, margins.min())
         assert abs(g["avg_logprob"] - r["avg_logprob"]) <= 5e-3
+        compared.append(len(r["tokens"]))
+    # the identity check must not pass vacuously: most clips compared, early AND late finishers among them
+    assert len(compared) >= 4 and len(set(compared)) >= 2, compared
     # and alone == in the batch, bit for bit, for an early finisher and a late one
     short = min(range(len(refs)), key=lambda i: len(refs[i]["tokens"]))
     long_ = max(range(len(refs)), key=lambda i: len(refs[i]["tokens"]))

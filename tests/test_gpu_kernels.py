@@ -72,3 +72,50 @@ def test_native_sample_types_are_converted_like_dasp_sample():
     check(f32, f32)
     assert [hip.load_library().nh_sample_size(c) for c in range(11)] == [4, 8, 1, 2, 4, 8, 1, 2, 4, 8, 0]
     hm.close()
+
+
+_STRICT_CHILD = r"""
+import json, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import common
+from norma_amd import config, hip, synth
+out = {}
+for name, B, script_seed in (("test-d128", 5, 3), ("tiny.en", 3, 8)):
+    cfg = config.preset(name); tk = common.tokens_for(name)
+    script = common.transcript_script(tk, n_segments=3, words_per_segment=6, seed=script_seed)
+    for label, over in (("scripted", common.scripted_overrides(cfg, tk, script)), ("random", None)):
+        hm = common.build_hip(cfg, tk, overrides=over, max_batch=B)
+        hm.logmel([synth.synth_pcm(k) for k in range(B)]); hm.encode()
+        res = hm.decode_greedy(0 if label == "scripted" else 60)
+        out[name + "/" + label] = [[r["tokens"], r["avg_logprob"].hex(), r["no_speech_prob"].hex()] for r in res]
+        hm.close()
+out["lib"] = hip.LIB_PATH
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_strict_memory_model_build_gives_the_same_tokens_and_logprobs():
+    """k_decode.hip's one cross-workgroup hand-off (logit_step_kernel: 8 workgroups per sequence -> last arriver) has two
+    spellings: the gfx950 ISA-level default (sc1 stores, s_waitcnt vmcnt(0), relaxed ticket) and -DNH_STRICT_MEMORY_MODEL
+    (RELEASE ticket + ACQUIRE fence).  The Makefile builds both on every build; this runs the strict library
+    (NORMA_HIP_LIB) in a child process and compares tokens and log-probs with the default library bit for bit."""
+    import json
+    import sys
+    from norma_amd import hip
+    if not os.path.exists(hip.STRICT_LIB_PATH):
+        pytest.fail(f"{hip.STRICT_LIB_PATH} not built (make -C norma_amd/csrc)")
+    outs = []
+    for lib in (None, hip.STRICT_LIB_PATH):
+        env = dict(os.environ)
+        env.pop("NORMA_HIP_LIB", None)
+        if lib:
+            env["NORMA_HIP_LIB"] = lib
+        p = subprocess.run([sys.executable, "-c", _STRICT_CHILD, common.ROOT], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-3000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
+        outs.append(json.loads(line[len("RESULT "):]))
+    default, strict = outs
+    assert strict.pop("lib").endswith("libnorma_hip_strict.so") and default.pop("lib").endswith("libnorma_hip.so")
+    assert default == strict
+    assert any(len(r[0]) > 20 for r in default["tiny.en/scripted"])

@@ -4,7 +4,13 @@
 // The tool runs the fc2-shaped GEMM back to back on a stream confined to the first E CUs (hipExtStreamCreateWithCUMask;
 // bit i = CU i / 8 of XCD i % 8) and a dependent chain of small streaming kernels (160 workgroups x 256 threads reading
 // 16 MB each) on a stream confined to the other 256 - E; GEMM and chain time alone and together, masked and unmasked.
-// `cumask destroy` also destroys the masked streams: on ROCm 7.2 the second hipStreamDestroy did not return.
+// `cumask destroy` also destroys the masked streams.  r02 (gpurun_out/cumask_destroy.txt): with the timing events that had been
+// recorded on them still alive, destroying `se` returned and destroying `sd` never did.  Nothing was queued (run() ends in
+// hipDeviceSynchronize), the two masks are disjoint and non-empty on every XCD (bits [0, E) and [E, 256): CUs 0 .. E/8 - 1 and
+// E/8 .. 31 of each XCD), the GEMM's persistent grid is E workgroups = the CUs its stream can reach.  What was left referring
+// to `sd` when it was destroyed were the events c0 / c1 (last recorded on it) -- so the teardown now follows the order that
+// needs no such reference: synchronise, destroy the events recorded on the masked streams, then the streams, last created
+// first.  `cumask destroy <order>`: order 0 = that (default), 1 = events first but streams in creation order, 2 = r02's order.
 // Outcome (profiles/r02_cumask.txt): the chain runs 4.7x slower beside an unmasked GEMM and only 1.3x slower
 // beside a masked one that itself loses 8 % -- but with the real decode step the job's throughput did not move, with
 // masks (decode on D CUs is per-CU fetch bound: 340 us per token on 128 CUs, 466 on 64, against 243 on 256) or with the
@@ -49,7 +55,10 @@ int main(int argc, char **argv) {
     p.A = A; p.lda = K; p.a_rpb = M; p.W = W; p.bias = bias; p.M = M; p.N = N; p.K = K; p.epi = EPI_RESID_F32;
     p.out[0] = X; p.seg_n = N; p.ldo = N; p.o_rpb = M; p.vt_seg = -1; p.S = 1500; p.H = 20;
     hipEvent_t g0, g1, c0, c1;
-    hipEventCreate(&g0); hipEventCreate(&g1); hipEventCreate(&c0); hipEventCreate(&c1);
+    auto make_events = [&]() { hipEventCreate(&g0); hipEventCreate(&g1); hipEventCreate(&c0); hipEventCreate(&c1); };
+    auto drop_events = [&]() { CK(hipEventDestroy(g0)); CK(hipEventDestroy(g1)); CK(hipEventDestroy(c0)); CK(hipEventDestroy(c1)); };
+    make_events();
+    const int order = argc > 2 ? atoi(argv[2]) : 0;
     auto run = [&](const char *name, hipStream_t sg, hipStream_t sc, int cus, bool do_gemm, bool do_chain) {
         p.cus = cus;
         if (do_gemm) { for (int i = 0; i < 3; i++) launch_gemm(p, sg); }
@@ -80,7 +89,13 @@ int main(int argc, char **argv) {
         snprintf(nm, sizeof nm, "E=%d D=%d: gemm alone (masked)", E, D); run(nm, se, sd, E, true, false);
         snprintf(nm, sizeof nm, "E=%d D=%d: chain alone (masked)", E, D); run(nm, se, sd, E, false, true);
         snprintf(nm, sizeof nm, "E=%d D=%d: both", E, D); run(nm, se, sd, E, true, true);
-        if (argc > 1) { CK(hipStreamDestroy(se)); printf("destroyed se\n"); CK(hipStreamDestroy(sd)); printf("destroyed sd\n"); }
+        if (argc > 1) {
+            CK(hipDeviceSynchronize());
+            if (order != 2) { drop_events(); printf("destroyed the events recorded on se / sd\n"); }
+            if (order == 0) { CK(hipStreamDestroy(sd)); printf("destroyed sd\n"); CK(hipStreamDestroy(se)); printf("destroyed se\n"); }
+            else { CK(hipStreamDestroy(se)); printf("destroyed se\n"); CK(hipStreamDestroy(sd)); printf("destroyed sd\n"); }
+            if (order != 2) make_events();
+        }
     }
     return 0;
 }
