@@ -13,6 +13,11 @@ Workloads (`--workload`):
               the results are gathered on all ranks over RCCL inside the timed region -- strong scaling.
   lv3b64      BASELINE.json configs[4]: large-v3 multilingual, 64 chunks split over the ranks (8 per GPU at N = 8),
               language detection + timestamp decoding, results gathered -- strong scaling.
+  varlen      (not a BASELINE config) distil-large-v3, 64 chunks whose transcripts END AT DIFFERENT STEPS (the audio votes
+              text-vs-eot at nine steps): arrival-order batches against length-bucketed batches dealt with
+              shard.partition_balanced, wasted row-steps of each reported in `extra`.
+`--rank-share r/N` (strong workloads): run, on this one GPU, only the chunks rank r of an N-rank job would get -- the
+per-rank time a whole-node run would be bounded by, without the node.
 
 Ranks: `python bench.py --gpus N` starts N fresh child processes by itself (one per GPU; the parent never touches
 the GPU, torch or HIP) unless it is already running under a launcher (WORLD_SIZE set, e.g. torch.distributed.run),
@@ -39,6 +44,10 @@ WORKLOADS = {
     "b32": ("distil-large-v3", None, "weak"),
     "longform20": ("distil-large-v3", 20, "strong"),
     "lv3b64": ("large-v3", 64, "strong"),
+    # not a BASELINE config: the reference's decode loop ends per sequence at eot (model.rs:317); this job's 64 chunks end at
+    # different steps (audio-decided eot votes), so it measures what a batch that waits for its longest sequence wastes and
+    # what dealing the chunks by measured length (shard.partition_balanced / length_buckets) recovers
+    "varlen": ("distil-large-v3", 64, "strong"),
 }
 HBM_PEAK_TBS = 8.0      # MI355X_MICROARCH.md
 MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 (no sparsity)
@@ -60,9 +69,16 @@ def parse_args(argv=None):
                          "MFMA-bound encoder of the next.  1 = one batch at a time")
     ap.add_argument("--no-graphs", action="store_true", help="A/B: launch every decode-step kernel eagerly (NH_OPT_DECODE_GRAPHS = 0)")
     ap.add_argument("--no-ln-fusion", action="store_true", help="A/B: stand-alone decoder LayerNorm kernels (NH_OPT_FUSE_DECODE_LAYERNORM = 0)")
+    ap.add_argument("--private-weights", action="store_true",
+                    help="A/B: every pipeline loads its own copy of the weights (r02 behaviour) instead of sharing one (nh_create_shared)")
     ap.add_argument("--no-single-extra", action="store_true", help="skip the one-batch-at-a-time measurement in `extra`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-new-tokens", type=int, default=96)
+    ap.add_argument("--rank-share", default=None, metavar="r/N",
+                    help="strong workloads, --gpus 1: run only the chunks rank r of an N-rank job would get (no gather); the "
+                         "line reports that share's time and the job throughput N such ranks would give")
+    ap.add_argument("--balance", action="store_true",
+                    help="workload varlen: `value` is the length-bucketed / partition_balanced pass (default: arrival order)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: the ranks rendezvous (gloo), partition the job, exchange placeholder results "
                          "through the real gather and print the JSON line with value null (CPU rehearsal of the N > 1 path)")
@@ -189,24 +205,44 @@ def worker(args):
         parts = shard.partition(job_chunks, world)
         first, B = parts[rank]
         total_chunks = job_chunks
+        if args.rank_share:                     # one rank's share of an N-rank job, alone on this GPU
+            if world != 1:
+                raise SystemExit("bench.py: --rank-share needs --gpus 1")
+            sr, sn = (int(x) for x in args.rank_share.split("/"))
+            first, B = shard.partition(job_chunks, sn)[sr]
+            total_chunks = B
     gather_dev = dev if backend == "nccl" else None
 
+    if args.workload == "varlen" and not args.dry_run:
+        return worker_varlen(args, cfg, tk, world, rank, local_rank, dev, backend, gather_dev)
+
     if args.dry_run:
-        local = [dict(tokens=[tk.sot, tk.transcribe, 1000 + first + i, tk.eot], avg_logprob=-0.5, no_speech_prob=0.0,
-                      no_speech_exit=False) for i in range(B)]
+        assign = None
+        if args.workload == "varlen":   # placeholder decode lengths -> the real partition_balanced + reordering gather
+            fake_steps = [20 + (k * 37) % 300 for k in range(job_chunks)]
+            assign = shard.partition_balanced(fake_steps, world)
+            mine = assign[rank]
+        else:
+            mine = list(range(first, first + B))
+        local = [dict(tokens=[tk.sot, tk.transcribe, 1000 + k, tk.eot], avg_logprob=-0.5, no_speech_prob=0.0,
+                      no_speech_exit=False) for k in mine]
         allr = local
         if world > 1:
             dist.barrier()
-            allr = shard.gather_results(local, total_chunks, C, device=None) if job_chunks is not None else local
+            allr = shard.gather_results(local, total_chunks, C, device=None, assignment=assign) if job_chunks is not None else local
             dist.barrier()
         if rank == 0:
             out = {"metric": f"audio-sec/wall-sec (xRT) {model_name} fp16", "value": None, "unit": "audio-sec/wall-sec",
                    "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "dry_run": True, "scaling": scaling,
-                   "config": {"workload": args.workload, "chunks_per_rank": [c for _, c in shard.partition(total_chunks, world)]
+                   "config": {"workload": args.workload, "chunks_per_rank": ([len(a) for a in assign] if assign is not None else
+                                                                              [c for _, c in shard.partition(total_chunks, world)])
                               if job_chunks is not None else [B] * world, "chunks": total_chunks},
                    "gathered": len(allr) if job_chunks is not None else None}
             if job_chunks is not None:
                 out["gathered_third_tokens"] = [r["tokens"][2] for r in allr]
+            if assign is not None:
+                out["balanced_loads"] = [sum(fake_steps[i] for i in a) for a in assign]
+                out["contiguous_loads"] = [sum(fake_steps[s0:s0 + c]) for s0, c in shard.partition(job_chunks, world)]
             print(json.dumps(out), flush=True)
         if world > 1:
             dist.destroy_process_group()
@@ -220,9 +256,11 @@ def worker(args):
     P = max(1, args.pipelines) if job_chunks is None else 1   # the strong workloads run their job once per step
     headline = args.workload == "b32" and args.model is None
     hms = []
-    for _ in range(P):
-        h = hip.HipWhisper(cfg, device=local_rank, max_batch=max(B, 1))
-        h.set_mel_filters(assets_io.mel_filters(cfg.num_mel_bins))
+    for i in range(P):
+        shared = hms[0] if (i > 0 and not args.private_weights) else None   # one weight set per device (nh_create_shared)
+        h = hip.HipWhisper(cfg, device=local_rank, max_batch=max(B, 1), share_with=shared)
+        if shared is None:
+            h.set_mel_filters(assets_io.mel_filters(cfg.num_mel_bins))
         h.set_tokens(tk, -1 if multilingual else tk.en, tk.transcribe)
         if args.no_graphs:
             h.set_option(hip.NH_OPT_DECODE_GRAPHS, 0)
@@ -237,7 +275,7 @@ def worker(args):
         om = O.OracleModel(cfg, tk, tk.en, tk.transcribe)
     for name, arr in synth.synth_weights(cfg, seed=0):  # seed-0 N(0, 0.02^2), fp16-representable
         a16 = arr.astype(np.float16)
-        for h in hms:
+        for h in (hms if args.private_weights else hms[:1]):
             h.load_tensor(name, a16)
         if om is not None:
             om.set_tensor(name, arr)
@@ -413,7 +451,8 @@ def worker(args):
                                    ("to the 447-token cap (seed-0 random weights never emit eot)" if args.max_new_tokens == 0
                                     else f"{args.max_new_tokens} new tokens"),
                        "name": args.workload, "batch_per_gpu": B, "chunks": total_chunks, "clip_seconds": 30,
-                       "decode_tokens": n_tok, "parallelism": f"chunk-dp{world}", "batches_in_flight_per_gpu": P},
+                       "decode_tokens": n_tok, "parallelism": f"chunk-dp{world}", "batches_in_flight_per_gpu": P,
+                       "weight_sets_per_gpu": P if args.private_weights else 1},
             "phases_ms": {k: tm[k] for k in ("mel_ms", "encoder_ms", "cross_kv_ms", "decode_ms")} if tm else None,
             "decode_steps": tm["decode_steps"] if tm else 0,
             "roofline": {"bound": "mfma", "kernel": "gemm256_f16_kernel", "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS,
@@ -428,6 +467,13 @@ def worker(args):
                          "phases": phases, "time_weighted_frac": time_weighted},
             "extra": extra, "model_build_s": t_build,
         }
+        if args.rank_share:
+            sr, sn = (int(x) for x in args.rank_share.split("/"))
+            out["rank_share"] = {"rank": sr, "of": sn, "chunks": B, "job_chunks": job_chunks, "ms": dt / args.steps * 1e3,
+                                 "implied_job_xrt": job_chunks * 30.0 / (dt / args.steps),
+                                 "note": "time of ONE rank's share alone on one GPU; rank 0 holds the largest share, so "
+                                         "job_chunks x 30 s / this time is the whole-job rate N such ranks would reach "
+                                         "(gather excluded: <= 115 KB)"}
         if args.print_tokens_hash:
             out["tokens_hash"] = tokens_hash(res)
             out["results"] = len(res)
@@ -454,6 +500,136 @@ def worker(args):
         dist.destroy_process_group()
     for h in hms:
         h.close()
+    return 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# workload varlen: sequences that end at different steps
+# ---------------------------------------------------------------------------------------------------------------------
+VARLEN_EOT_STEPS = [40, 55, 70, 85, 100, 120, 150, 200, 280]   # audio-decided (text | eot) votes at these text steps
+VARLEN_TEXT_STEPS = 360
+
+
+def varlen_spec(cfg, tk):
+    """tests/common.py:audio_overrides spec: one text pair at every step but nine, where the second token of the pair is
+    eot -- about half of the clips still running stop at each of them (which half is decided by the clip's audio)."""
+    import numpy as np
+    rng = np.random.default_rng(77)
+    sup = set(cfg.suppress_tokens)
+
+    def tok():
+        while True:
+            t = int(rng.integers(300, 40000))
+            if t not in sup:
+                return t
+    pairs, seq = [[tok(), tok(), 0]], [0] * VARLEN_TEXT_STEPS
+    for j, e in enumerate(VARLEN_EOT_STEPS, start=1):
+        pairs.append([tok(), tk.eot, j])
+        seq[e] = j
+    return dict(conv_amp=10.0, pos_rms=4.0, peak_logit=14.0, gamma=0.0, segment=20, pairs=pairs, att_ref=[0.0] * cfg.d_model, seq=seq)
+
+
+def worker_varlen(args, cfg, tk, world, rank, local_rank, dev, backend, gather_dev):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from norma_amd import assets_io, hip, shard, synth
+    import common
+    job, C, BMAX = WORKLOADS["varlen"][1], cfg.max_target_positions, args.batch
+    hm = hip.HipWhisper(cfg, device=local_rank, max_batch=BMAX)
+    hm.set_mel_filters(assets_io.mel_filters(cfg.num_mel_bins))
+    hm.set_tokens(tk, tk.en, tk.transcribe)
+    spec = varlen_spec(cfg, tk)
+    over0, _ = common.audio_overrides(cfg, tk, spec)
+    for name, arr in synth.synth_weights(cfg, 0, over0):
+        hm.load_tensor(name, arr.astype(np.float16))
+    # calibrate the votes on chunks 0 .. 15 (every rank does the same: the kernels are deterministic, so all ranks end up
+    # with bit-identical weights): reference read-out and gain of the last decoder layer's cross-attention (common.py)
+    hm.logmel([synth.synth_pcm(k) for k in range(16)]); hm.encode()
+    means = [hm.encoder_output(b).mean(0, keepdims=True) for b in range(16)]
+    common.audio_calibrate(cfg, means, spec, vote=1.5)
+    over, _ = common.audio_overrides(cfg, tk, spec)
+    lastp = f"model.decoder.layers.{cfg.decoder_layers - 1}.encoder_attn.out_proj"
+    for leaf in (".weight", ".bias"):
+        hm.load_tensor(lastp + leaf, over[lastp + leaf].astype(np.float16))
+    pcm_all = torch.from_numpy(np.stack([synth.synth_pcm(k) for k in range(job)])).to(dev)   # the whole job, resident in HBM
+    stage = torch.empty((BMAX, synth.N_SAMPLES), dtype=torch.float32, device=dev)
+    torch.cuda.synchronize()
+
+    def run(assign, batches_of):
+        """one pass over the job: this rank's chunks in batches, then the gather"""
+        mine, res, batches = assign[rank], {}, batches_of(assign[rank])
+        for b in batches:
+            idx = torch.tensor(b, dtype=torch.long, device=dev)
+            torch.index_select(pcm_all, 0, idx, out=stage[:len(b)])
+            torch.cuda.synchronize()
+            out = hm.transcribe_batch_device(stage.data_ptr(), [synth.N_SAMPLES] * len(b), synth.N_SAMPLES, 0)
+            res.update(zip(b, out))
+        local = [res[k] for k in mine]
+        if world > 1:
+            return shard.gather_results(local, job, C, device=gather_dev, assignment=assign), batches
+        return [res[k] for k in range(job)], batches
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(); hm.synchronize()
+
+    def timed(assign, batches_of):
+        run(assign, batches_of); barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            allr, batches = run(assign, batches_of)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return allr, batches, dt / args.steps
+
+    contiguous = [list(range(s0, s0 + c)) for s0, c in shard.partition(job, world)]
+    arrival = lambda mine: [mine[i:i + BMAX] for i in range(0, len(mine), BMAX)]
+    hm.set_profile_gemm(True)
+    res_a, _, t_a = timed(contiguous, arrival)
+    steps = [len(r["tokens"]) - 3 for r in res_a]              # decode steps every chunk needs (prompt excluded)
+    balanced = shard.partition_balanced(steps, world)           # measured lengths -> ranks (LPT), then buckets inside a rank
+    res_b, _, t_b = timed(balanced, lambda mine: shard.length_buckets(mine, steps, BMAX))
+    identical = [a["tokens"] for a in res_a] == [b["tokens"] for b in res_b]
+    tm = hm.timings()
+    if rank == 0:
+        def summary(assign, batches_of, t):
+            run_rs = need_rs = 0
+            loads = []
+            for r in range(world):
+                bs = batches_of(assign[r])
+                a, b = shard.wasted_row_steps(bs, steps)
+                run_rs += a; need_rs += b
+                loads.append(sum(max(steps[i] for i in bt) for bt in bs if bt))
+            return {"xrt": job * 30.0 / t, "ms_per_job": t * 1e3, "row_steps_run": run_rs, "row_steps_needed": need_rs,
+                    "wasted_row_step_frac": 1.0 - need_rs / max(run_rs, 1), "decode_steps_per_rank": loads}
+        sa = summary(contiguous, arrival, t_a)
+        sb = summary(balanced, lambda mine: shard.length_buckets(mine, steps, BMAX), t_b)
+        t_val = t_b if args.balance else t_a
+        gemm_tflops = tm["gemm_flops"] / (tm["gemm_ms"] * 1e-3) / 1e12 if tm["gemm_ms"] > 0 else 0.0
+        out = {"metric": "audio-sec/wall-sec (xRT) distil-large-v3 fp16, variable decode lengths", "value": job * 30.0 / t_val,
+               "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps, "warmup": 1, "ms_per_step": t_val * 1e3,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+               "config": {"workload": f"{job} x 30 s chunks whose transcripts end at different steps (audio-decided eot votes at text "
+                                      f"steps {VARLEN_EOT_STEPS}), batches of <= {BMAX}, " +
+                                      ("length-bucketed batches dealt with partition_balanced" if args.balance else "arrival-order batches"),
+                          "name": "varlen", "chunks": job, "batch_per_gpu": BMAX, "parallelism": f"chunk-dp{world}"},
+               "roofline": {"bound": "mfma", "kernel": "gemm256_f16_kernel", "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS,
+                            "unit": "TFLOP/s", "frac": gemm_tflops / MFMA_PEAK_TFLOPS, "traffic": None},
+               "cpu_baseline": None,
+               "extra": {"decode_steps": {"min": min(steps), "median": int(np.median(steps)), "mean": float(np.mean(steps)), "max": max(steps),
+                                          "histogram": {str(v): steps.count(v) for v in sorted(set(steps))}},
+                         "arrival_order": sa, "length_bucketed": sb, "same_tokens_both_ways": identical}}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    hm.close()
     return 0
 
 

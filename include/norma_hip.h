@@ -14,6 +14,7 @@
  * What each entry point replaces:
  *   nh_create / nh_destroy        SelectedDevice -> device (src/models/mod.rs:47-55) and
  *                                 Whisper::load (src/models/whisper/monolingual.rs:371-373)
+ *   nh_create_shared              (no counterpart: the reference is single-stream) further contexts over one weight set
  *   nh_load_tensor                VarBuilder::from_mmaped_safetensors tensor reads by HF name
  *                                 (monolingual.rs:237-239)
  *   nh_set_mel_filters            the include_bytes! filterbank (monolingual.rs:351-362)
@@ -87,6 +88,14 @@ typedef struct nh_decode_result {
 /* ---- lifetime -------------------------------------------------------------------------------- */
 /* device_ordinal: SelectedDevice::Rocm(ord).  max_batch: chunks processed per call (>= 1). */
 int nh_create(int device_ordinal, const nh_config *cfg, int max_batch, nh_ctx **out);
+/* Another context on the same device over the SAME weights as `parent` (the reference runs one stream per model,
+ * src/lib.rs:462-464; a chunk-parallel caller keeps several batches in flight per GPU and must not pay 1.5 - 3.1 GB of HBM and a
+ * separate weight stream per batch).  The new context has its own streams, workspaces, K/V caches, tokens (nh_set_tokens) and
+ * decode state; everything nh_load_tensor / nh_set_mel_filters fill in is shared and reference counted: it is freed when the
+ * last context of the family is destroyed, in any order.  Loading through ANY context of a family is seen by all of them and
+ * must not overlap with a running call on another one (load once, then run); the run-time calls of different contexts may
+ * overlap freely, one host thread per context. */
+int nh_create_shared(nh_ctx *parent, int max_batch, nh_ctx **out);
 void nh_destroy(nh_ctx *ctx);
 const char *nh_last_error(const nh_ctx *ctx); /* ctx may be NULL: error of a failed nh_create */
 /* 1 when built for and running on a gfx950 device visible to HIP, else 0 (no side effects). */

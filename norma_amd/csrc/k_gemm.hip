@@ -406,6 +406,13 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmParams p) {
     pp_tile(vb, ntn, ntm, tm, tn);
     PPSource sg = pp_source(p, tm * G2_BM, tn * G2_BN);
     pp_prologue(p, wbase, sg);
+#ifdef G2_STAMPS   // diagnostic build (tools/gstamps): when does every workgroup start, finish each tile, and on which XCD
+    int stamp_n = 0;
+    if (threadIdx.x == 0 && p.dbg) {
+        p.dbg[blockIdx.x * 32 + 0] = __builtin_amdgcn_s_memrealtime();
+        p.dbg[blockIdx.x * 32 + 1] = __builtin_amdgcn_s_getreg(6164);   // HW_REG_XCC_ID[3:0]
+    }
+#endif
     for (;;) {
         const int m0 = tm * G2_BM, n0 = tn * G2_BN;
         f32x4 acc[8][4];
@@ -545,6 +552,9 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmParams p) {
                 }
             }
         }
+#ifdef G2_STAMPS
+        if (threadIdx.x == 0 && p.dbg && stamp_n < 28) { p.dbg[blockIdx.x * 32 + 4 + stamp_n] = __builtin_amdgcn_s_memrealtime(); stamp_n++; p.dbg[blockIdx.x * 32 + 2] = stamp_n; }
+#endif
         if (!more) break;
         vb = nvb;
     }

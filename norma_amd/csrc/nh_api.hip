@@ -9,6 +9,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <memory>
+#include <mutex>
 #include <set>
 #include <string>
 #include <vector>
@@ -32,30 +34,55 @@ struct LnW { float *w = nullptr, *b = nullptr; };
 struct EncLayer { LnW ln1, ln2; LinW qkv, o, fc1, fc2; };
 struct DecLayer { LnW ln1, ln2, ln3; LinW qkv, o, cq, ckv, co, fc1, fc2; half_t *ck = nullptr, *cv = nullptr, *sk = nullptr, *sv = nullptr; };
 
-struct nh_ctx {
+// The read-only half of a context: everything nh_load_tensor / nh_set_mel_filters fill in.  Owned through a shared_ptr, so
+// that several contexts on one device (nh_create_shared) run on ONE copy of the weights: bench.py keeps three batches in
+// flight per GPU, and three private copies meant 3 x 1.5 GB of HBM and three different address ranges for the 225 MB of
+// decoder weights + embedding every in-flight decode streams per token.  The contexts hold plain pointer VIEWS of these
+// tables (the same LinW / LnW structs as before); `version` tells a context that the tables moved under it.
+struct nh_model {
     int dev = 0;
-    hipStream_t st = nullptr;   // log-mel + encoder + cross K/V
-    hipStream_t sd = nullptr;   // decode loop: highest priority, so its small latency-bound kernels are dispatched ahead of
-                                // other contexts' encoder tiles when several batches are in flight on one GPU
-    hipEvent_t enc_done = nullptr;
     nh_config c{};
-    int B = 1;
-    std::string err;
     std::vector<void *> allocs;
-    // weights
     LinW conv1, conv2;
     float *enc_pos = nullptr;
     std::vector<EncLayer> enc;
     LnW ln_post, dec_ln;
     half_t *tok_emb = nullptr, *dec_pos = nullptr;
     half_t *tok_emb_t = nullptr;     // tile-major repack of the tied embedding (logits GEMV)
+    std::vector<DecLayer> dec;       // weights only (ck / cv / sk / sv stay per context)
     bool dec_tiled_valid = false;    // the repacks mirror the row-major decoder weights loaded so far
-    std::vector<DecLayer> dec;
     std::set<std::string> expected, loaded;
-    // mel
     MelTables mt{};
     int32_t *mel_grp = nullptr;
     bool have_filters = false;
+    int version = 1;                 // bumped whenever a pointer in here changes (lazy repack allocation, new filters)
+    std::mutex mu;                   // guards loaded / dec_tiled_valid / version and the lazy repack
+    ~nh_model() {
+        hipSetDevice(dev);
+        for (void *p : allocs) hipFree(p);
+    }
+};
+
+struct nh_ctx {
+    int dev = 0;
+    std::shared_ptr<nh_model> mdl;
+    int view_version = 0;       // nh_model::version the pointer views below were copied at
+    hipStream_t st = nullptr;   // the context's stream: log-mel, encoder, cross K/V, decode loop
+    hipStream_t sd = nullptr;   // alias of st (the decode loop's launches are written against sd; see build_context)
+    hipEvent_t enc_done = nullptr;
+    nh_config c{};
+    int B = 1;
+    std::string err;
+    std::vector<void *> allocs;
+    // weights: VIEWS of mdl's tables (refresh_views); dec[i] also carries this context's own K/V caches
+    LinW conv1, conv2;
+    float *enc_pos = nullptr;
+    std::vector<EncLayer> enc;
+    LnW ln_post, dec_ln;
+    half_t *tok_emb = nullptr, *dec_pos = nullptr;
+    half_t *tok_emb_t = nullptr;
+    std::vector<DecLayer> dec;
+    // mel
     float *pcm = nullptr;
     void *raw = nullptr; size_t raw_bytes = 0;   // native-sample staging of nh_logmel_samples
     int32_t *nsamp = nullptr;
@@ -111,14 +138,16 @@ static void drop_graphs(nh_ctx *ctx) {
 }
 
 template <typename T>
-static T *dalloc(nh_ctx *ctx, size_t n, bool zero = true) {
+static T *dalloc_into(std::vector<void *> &allocs, size_t n, bool zero = true) {
     void *p = nullptr;
     if (n == 0) n = 1;
     if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr;
     if (zero) hipMemset(p, 0, n * sizeof(T));
-    ctx->allocs.push_back(p);
+    allocs.push_back(p);
     return reinterpret_cast<T *>(p);
 }
+template <typename T>
+static T *dalloc(nh_ctx *ctx, size_t n, bool zero = true) { return dalloc_into<T>(ctx->allocs, n, zero); }
 
 // ---- expected tensor names (the set candle reads) ---------------------------------
 static void add_lin(std::set<std::string> &s, const std::string &p, bool bias = true) {
@@ -128,17 +157,17 @@ static void add_lin(std::set<std::string> &s, const std::string &p, bool bias = 
 static void add_attn(std::set<std::string> &s, const std::string &p) {
     add_lin(s, p + ".q_proj"); add_lin(s, p + ".k_proj", false); add_lin(s, p + ".v_proj"); add_lin(s, p + ".out_proj");
 }
-static void build_expected(nh_ctx *ctx) {
-    auto &s = ctx->expected;
+static void build_expected(nh_model *m) {
+    auto &s = m->expected;
     add_lin(s, "model.encoder.conv1"); add_lin(s, "model.encoder.conv2");
-    for (int i = 0; i < ctx->c.encoder_layers; i++) {
+    for (int i = 0; i < m->c.encoder_layers; i++) {
         std::string p = "model.encoder.layers." + std::to_string(i);
         add_attn(s, p + ".self_attn"); add_lin(s, p + ".self_attn_layer_norm");
         add_lin(s, p + ".fc1"); add_lin(s, p + ".fc2"); add_lin(s, p + ".final_layer_norm");
     }
     add_lin(s, "model.encoder.layer_norm");
     s.insert("model.decoder.embed_tokens.weight"); s.insert("model.decoder.embed_positions.weight");
-    for (int i = 0; i < ctx->c.decoder_layers; i++) {
+    for (int i = 0; i < m->c.decoder_layers; i++) {
         std::string p = "model.decoder.layers." + std::to_string(i);
         add_attn(s, p + ".self_attn"); add_lin(s, p + ".self_attn_layer_norm");
         add_attn(s, p + ".encoder_attn"); add_lin(s, p + ".encoder_attn_layer_norm");
@@ -165,19 +194,18 @@ extern "C" void nh_destroy(nh_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->dev);
     if (ctx->st) hipStreamSynchronize(ctx->st);
-    if (ctx->sd) hipStreamSynchronize(ctx->sd);
     for (void *p : ctx->allocs) hipFree(p);
     drop_graphs(ctx);
     if (ctx->h_done) hipHostFree(ctx->h_done);
     for (auto &e : ctx->ev) if (e) hipEventDestroy(e);
     for (auto &e : ctx->gemm_ev) hipEventDestroy(e);
     if (ctx->enc_done) hipEventDestroy(ctx->enc_done);
-    if (ctx->sd) hipStreamDestroy(ctx->sd);
-    if (ctx->st) hipStreamDestroy(ctx->st);
+    if (ctx->st) hipStreamDestroy(ctx->st);   // sd is the same stream
+    ctx->mdl.reset();  // the last context of a model frees its weights (~nh_model)
     delete ctx;
 }
 
-static int build_mel_tables(nh_ctx *ctx) {
+static bool build_mel_tables(nh_model *m, std::string &err) {
     // host tables with libm, the same f32 expressions candle evaluates (see k_mel.hip)
     std::vector<float> hann(400), dc(625), dsn(625), twc(375), tws(375);
     const float two_pi = (float)M_PI + (float)M_PI;
@@ -196,15 +224,140 @@ static int build_mel_tables(nh_ctx *ctx) {
         }
         off += h;
     }
-    float *d_h = dalloc<float>(ctx, 400), *d_dc = dalloc<float>(ctx, 625), *d_ds = dalloc<float>(ctx, 625);
-    float *d_tc = dalloc<float>(ctx, 375), *d_ts = dalloc<float>(ctx, 375);
-    if (!d_h || !d_dc || !d_ds || !d_tc || !d_ts) return ctx->fail(NH_ERR_NOMEM, "hipMalloc(mel tables)");
-    HIPCHK(hipMemcpy(d_h, hann.data(), 400 * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_dc, dc.data(), 625 * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_ds, dsn.data(), 625 * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_tc, twc.data(), 375 * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d_ts, tws.data(), 375 * 4, hipMemcpyHostToDevice));
-    ctx->mt.hann = d_h; ctx->mt.dft_cos = d_dc; ctx->mt.dft_sin = d_ds; ctx->mt.tw_cos = d_tc; ctx->mt.tw_sin = d_ts;
+    float *d_h = dalloc_into<float>(m->allocs, 400), *d_dc = dalloc_into<float>(m->allocs, 625), *d_ds = dalloc_into<float>(m->allocs, 625);
+    float *d_tc = dalloc_into<float>(m->allocs, 375), *d_ts = dalloc_into<float>(m->allocs, 375);
+    if (!d_h || !d_dc || !d_ds || !d_tc || !d_ts) { err = "hipMalloc(mel tables)"; return false; }
+    if (hipMemcpy(d_h, hann.data(), 400 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_dc, dc.data(), 625 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ds, dsn.data(), 625 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_tc, twc.data(), 375 * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(d_ts, tws.data(), 375 * 4, hipMemcpyHostToDevice) != hipSuccess) { err = "hipMemcpy(mel tables)"; return false; }
+    m->mt.hann = d_h; m->mt.dft_cos = d_dc; m->mt.dft_sin = d_ds; m->mt.tw_cos = d_tc; m->mt.tw_sin = d_ts;
+    return true;
+}
+
+// the weight tables of one model on one device (zero-filled until nh_load_tensor fills them)
+static std::shared_ptr<nh_model> build_model(int device_ordinal, const nh_config *cfg, std::string &err, int &code) {
+    auto m = std::make_shared<nh_model>();
+    m->dev = device_ordinal; m->c = *cfg;
+    const int d = cfg->d_model, V = cfg->vocab_size, nm = cfg->num_mel_bins, ctxlen = cfg->max_target_positions;
+    build_expected(m.get());
+    bool ok = true;
+#define MA(field, T, n) ok = ok && ((m->field = dalloc_into<T>(m->allocs, (size_t)(n))) != nullptr)
+#define ML(f, T, n) ok = ok && ((L.f = dalloc_into<T>(m->allocs, (size_t)(n))) != nullptr)
+    MA(conv1.w, half_t, (long)d * 3 * NH_MELP); MA(conv1.b, float, d);
+    MA(conv2.w, half_t, (long)d * 3 * d); MA(conv2.b, float, d);
+    MA(enc_pos, float, 1500L * d);
+    m->enc.resize(cfg->encoder_layers);
+    for (auto &L : m->enc) {
+        ML(ln1.w, float, d); ML(ln1.b, float, d); ML(ln2.w, float, d); ML(ln2.b, float, d);
+        ML(qkv.w, half_t, 3L * d * d); ML(qkv.b, float, 3 * d); ML(o.w, half_t, (long)d * d); ML(o.b, float, d);
+        ML(fc1.w, half_t, 4L * d * d); ML(fc1.b, float, 4 * d); ML(fc2.w, half_t, 4L * d * d); ML(fc2.b, float, d);
+    }
+    MA(ln_post.w, float, d); MA(ln_post.b, float, d); MA(dec_ln.w, float, d); MA(dec_ln.b, float, d);
+    MA(tok_emb, half_t, (long)V * d); MA(dec_pos, half_t, (long)ctxlen * d);
+    m->dec.resize(cfg->decoder_layers);
+    for (auto &L : m->dec) {
+        ML(ln1.w, float, d); ML(ln1.b, float, d); ML(ln2.w, float, d); ML(ln2.b, float, d); ML(ln3.w, float, d); ML(ln3.b, float, d);
+        ML(qkv.w, half_t, 3L * d * d); ML(qkv.b, float, 3 * d); ML(o.w, half_t, (long)d * d); ML(o.b, float, d);
+        ML(cq.w, half_t, (long)d * d); ML(cq.b, float, d); ML(ckv.w, half_t, 2L * d * d); ML(ckv.b, float, 2 * d);
+        ML(co.w, half_t, (long)d * d); ML(co.b, float, d);
+        ML(fc1.w, half_t, 4L * d * d); ML(fc1.b, float, 4 * d); ML(fc2.w, half_t, 4L * d * d); ML(fc2.b, float, d);
+    }
+    MA(mel_grp, int32_t, 2 * nm);
+#undef ML
+#undef MA
+    if (!ok) { err = "hipMalloc failed while sizing the model (out of device memory?)"; code = NH_ERR_NOMEM; return nullptr; }
+    {   // encoder sinusoids, recomputed in f32 exactly as candle's sinusoids() (SURVEY.md 3.3-2)
+        std::vector<float> pos(1500L * d);
+        int half = d / 2;
+        float inc = logf(10000.0f) / (float)(half - 1);
+        for (int p = 0; p < 1500; p++)
+            for (int i = 0; i < half; i++) {
+                float st = (float)p * expf((float)i * (-inc));
+                pos[(long)p * d + i] = sinf(st);
+                pos[(long)p * d + half + i] = cosf(st);
+            }
+        if (hipMemcpy(m->enc_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            err = "hipMemcpy(enc_pos) failed"; code = NH_ERR_HIP; return nullptr;
+        }
+    }
+    if (!build_mel_tables(m.get(), err)) { code = NH_ERR_NOMEM; return nullptr; }
+    return m;
+}
+
+// copy the model's pointer tables into the context's views (keeping the context's own K/V caches in dec[i])
+static void refresh_views(nh_ctx *ctx) {
+    nh_model &m = *ctx->mdl;
+    std::lock_guard<std::mutex> lk(m.mu);
+    ctx->conv1 = m.conv1; ctx->conv2 = m.conv2; ctx->enc_pos = m.enc_pos; ctx->enc = m.enc;
+    ctx->ln_post = m.ln_post; ctx->dec_ln = m.dec_ln; ctx->tok_emb = m.tok_emb; ctx->dec_pos = m.dec_pos; ctx->tok_emb_t = m.tok_emb_t;
+    ctx->dec.resize(m.dec.size());
+    for (size_t i = 0; i < m.dec.size(); i++) {
+        DecLayer v = m.dec[i];
+        v.ck = ctx->dec[i].ck; v.cv = ctx->dec[i].cv; v.sk = ctx->dec[i].sk; v.sv = ctx->dec[i].sv;
+        ctx->dec[i] = v;
+    }
+    ctx->view_version = m.version;
+}
+static inline void ensure_views(nh_ctx *ctx) { if (ctx->view_version != ctx->mdl->version) refresh_views(ctx); }
+
+// stream, workspaces and caches of one context over an existing model
+static int build_context(std::shared_ptr<nh_model> mdl, int max_batch, nh_ctx **out) {
+    const nh_config *cfg = &mdl->c;
+    const int d = cfg->d_model;
+    nh_ctx *ctx = new nh_ctx();
+    ctx->dev = mdl->dev; ctx->c = *cfg; ctx->B = max_batch; ctx->mdl = mdl;
+    auto bail = [&](int code) { g_create_error = ctx->err; nh_destroy(ctx); return code; };
+    if (hipSetDevice(ctx->dev) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(NH_ERR_HIP); }
+    // ONE stream per context (sd aliases st).  r02 gave the decode loop a stream of its own at the highest priority; r03
+    // measured what that costs: the runtime backs every stream with an HSA queue, the queues are spread over the command
+    // processor's pipes in CREATION ORDER, and when the decode streams of two contexts land on one pipe their kernel chains
+    // take turns instead of overlapping -- three batches in flight ran at 4810 audio-s/s instead of 6330 after a harmless
+    // reordering of nh_create (weights allocated before the streams), with no other change (profiles/r03_stream_order.txt:
+    // two streams per context in r02's order 6332, without priorities 6332, one or two throw-away streams in front 6338 /
+    // 6326, three 4782, decode stream created first 4785, ONE stream per context 6358).  Encoder and decode of one
+    // context are sequential anyway; with one queue per context three contexts plus the null stream fit the four pipes.
+    if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->enc_done, hipEventDisableTiming) != hipSuccess) {
+        ctx->err = "hipStreamCreateWithFlags failed"; return bail(NH_ERR_HIP);
+    }
+    ctx->sd = ctx->st;
+    for (auto &e : ctx->ev) hipEventCreate(&e);
+    const int B = max_batch, V = cfg->vocab_size, nm = cfg->num_mel_bins, ctxlen = cfg->max_target_positions;
+    const long M = (long)B * 1500;
+    ctx->VP = (V + 63) & ~63;
+    bool ok = true;
+#define DA(field, T, n) ok = ok && ((ctx->field = dalloc<T>(ctx, (size_t)(n))) != nullptr)
+    // this context's K/V caches: cross K/V of the current batch, self-attention cache
+    ctx->dec.resize(cfg->decoder_layers);
+    for (auto &L : ctx->dec) {
+#define DL(f, T, n) ok = ok && ((L.f = dalloc<T>(ctx, (size_t)(n))) != nullptr)
+        DL(ck, half_t, M * d); DL(cv, half_t, M * d);
+        DL(sk, half_t, (long)B * ctxlen * d); DL(sv, half_t, (long)B * ctxlen * d);
+#undef DL
+    }
+    // mel
+    DA(pcm, float, (long)B * NH_N_SAMPLES); DA(nsamp, int32_t, B); DA(mel32, float, (long)B * nm * NH_N_FRAMES);
+    DA(chunk_max, unsigned, B); DA(mel_img, half_t, (long)B * (NH_N_FRAMES + 2) * NH_MELP);
+    // encoder
+    DA(h1, half_t, (long)B * (NH_N_FRAMES + 2) * d); DA(x, float, M * d); DA(xn, half_t, M * d);
+    DA(q, half_t, M * d); DA(k, half_t, M * d); DA(vt, half_t, (long)B * d * NH_SP); DA(att, half_t, M * d);
+    DA(hid, half_t, M * 4 * d); DA(xa16, half_t, M * d); DA(xa32, float, M * d);
+    // decoder
+    DA(dx, float, (long)B * d); DA(dy32, float, (long)B * d); DA(logits, float, (long)B * ctx->VP);
+    DA(dxn, half_t, (long)B * d); DA(dq, half_t, (long)B * d); DA(datt, half_t, (long)B * d); DA(dhid, half_t, (long)B * 4 * d);
+    DA(ds.tokens, int32_t, (long)B * ctxlen); DA(ds.n_tokens, int32_t, B); DA(ds.done, int32_t, B);
+    DA(ds.have_last, int32_t, B); DA(ds.last_ts, int32_t, B); DA(ds.sum_logprob, double, B); DA(ds.no_speech, double, B);
+    DA(ds.n_active, int32_t, 1); DA(suppress, uint8_t, V); DA(lpart, float, (long)B * 64); DA(ltick, unsigned, B); DA(d_pos, int32_t, 4); DA(d_lang_tokens, int32_t, 256); DA(d_lang_out, int32_t, B); DA(d_lang_probs, float, (long)B * 256);
+#undef DA
+    if (!ok) { ctx->err = "hipMalloc failed while sizing the context (out of device memory?)"; return bail(NH_ERR_NOMEM); }
+    ctx->ds.suppress = ctx->suppress;
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_done), sizeof(int32_t) * 128, 0) != hipSuccess) {
+        ctx->err = "hipHostMalloc failed"; return bail(NH_ERR_NOMEM);
+    }
+    refresh_views(ctx);
+    *out = ctx;
     return NH_OK;
 }
 
@@ -224,88 +377,18 @@ extern "C" int nh_create(int device_ordinal, const nh_config *cfg, int max_batch
                          " (SelectedDevice::Rocm needs a visible MI355X; there is no CPU fallback)";
         return NH_ERR_HIP;
     }
-    nh_ctx *ctx = new nh_ctx();
-    ctx->dev = device_ordinal; ctx->c = *cfg; ctx->B = max_batch;
-    auto bail = [&](int code) { g_create_error = ctx->err; nh_destroy(ctx); return code; };
-    if (hipSetDevice(device_ordinal) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(NH_ERR_HIP); }
-    {
-        int lo = 0, hi = 0;  // numerically lower = higher priority
-        hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (hipStreamCreateWithPriority(&ctx->st, hipStreamNonBlocking, lo) != hipSuccess ||
-            hipStreamCreateWithPriority(&ctx->sd, hipStreamNonBlocking, hi) != hipSuccess ||
-            hipEventCreateWithFlags(&ctx->enc_done, hipEventDisableTiming) != hipSuccess) {
-            ctx->err = "hipStreamCreateWithPriority failed"; return bail(NH_ERR_HIP);
-        }
-    }
-    for (auto &e : ctx->ev) hipEventCreate(&e);
-    build_expected(ctx);
-    const int B = max_batch, V = cfg->vocab_size, nm = cfg->num_mel_bins, ctxlen = cfg->max_target_positions;
-    const long M = (long)B * 1500;
-    ctx->VP = (V + 63) & ~63;
-    bool ok = true;
-#define DA(field, T, n) ok = ok && ((ctx->field = dalloc<T>(ctx, (size_t)(n))) != nullptr)
-    // weights
-    DA(conv1.w, half_t, (long)d * 3 * NH_MELP); DA(conv1.b, float, d);
-    DA(conv2.w, half_t, (long)d * 3 * d); DA(conv2.b, float, d);
-    DA(enc_pos, float, 1500L * d);
-    ctx->enc.resize(cfg->encoder_layers);
-    for (auto &L : ctx->enc) {
-#define DL(f, T, n) ok = ok && ((L.f = dalloc<T>(ctx, (size_t)(n))) != nullptr)
-        DL(ln1.w, float, d); DL(ln1.b, float, d); DL(ln2.w, float, d); DL(ln2.b, float, d);
-        DL(qkv.w, half_t, 3L * d * d); DL(qkv.b, float, 3 * d); DL(o.w, half_t, (long)d * d); DL(o.b, float, d);
-        DL(fc1.w, half_t, 4L * d * d); DL(fc1.b, float, 4 * d); DL(fc2.w, half_t, 4L * d * d); DL(fc2.b, float, d);
-    }
-    DA(ln_post.w, float, d); DA(ln_post.b, float, d); DA(dec_ln.w, float, d); DA(dec_ln.b, float, d);
-    DA(tok_emb, half_t, (long)V * d); DA(dec_pos, half_t, (long)ctxlen * d);
-    ctx->dec.resize(cfg->decoder_layers);
-    for (auto &L : ctx->dec) {
-        DL(ln1.w, float, d); DL(ln1.b, float, d); DL(ln2.w, float, d); DL(ln2.b, float, d); DL(ln3.w, float, d); DL(ln3.b, float, d);
-        DL(qkv.w, half_t, 3L * d * d); DL(qkv.b, float, 3 * d); DL(o.w, half_t, (long)d * d); DL(o.b, float, d);
-        DL(cq.w, half_t, (long)d * d); DL(cq.b, float, d); DL(ckv.w, half_t, 2L * d * d); DL(ckv.b, float, 2 * d);
-        DL(co.w, half_t, (long)d * d); DL(co.b, float, d);
-        DL(fc1.w, half_t, 4L * d * d); DL(fc1.b, float, 4 * d); DL(fc2.w, half_t, 4L * d * d); DL(fc2.b, float, d);
-        DL(ck, half_t, M * d); DL(cv, half_t, M * d);
-        DL(sk, half_t, (long)B * ctxlen * d); DL(sv, half_t, (long)B * ctxlen * d);
-#undef DL
-    }
-    // mel
-    DA(pcm, float, (long)B * NH_N_SAMPLES); DA(nsamp, int32_t, B); DA(mel32, float, (long)B * nm * NH_N_FRAMES);
-    DA(chunk_max, unsigned, B); DA(mel_img, half_t, (long)B * (NH_N_FRAMES + 2) * NH_MELP);
-    DA(mel_grp, int32_t, 2 * nm);
-    // encoder
-    DA(h1, half_t, (long)B * (NH_N_FRAMES + 2) * d); DA(x, float, M * d); DA(xn, half_t, M * d);
-    DA(q, half_t, M * d); DA(k, half_t, M * d); DA(vt, half_t, (long)B * d * NH_SP); DA(att, half_t, M * d);
-    DA(hid, half_t, M * 4 * d); DA(xa16, half_t, M * d); DA(xa32, float, M * d);
-    // decoder
-    DA(dx, float, (long)B * d); DA(dy32, float, (long)B * d); DA(logits, float, (long)B * ctx->VP);
-    DA(dxn, half_t, (long)B * d); DA(dq, half_t, (long)B * d); DA(datt, half_t, (long)B * d); DA(dhid, half_t, (long)B * 4 * d);
-    DA(ds.tokens, int32_t, (long)B * ctxlen); DA(ds.n_tokens, int32_t, B); DA(ds.done, int32_t, B);
-    DA(ds.have_last, int32_t, B); DA(ds.last_ts, int32_t, B); DA(ds.sum_logprob, double, B); DA(ds.no_speech, double, B);
-    DA(ds.n_active, int32_t, 1); DA(suppress, uint8_t, V); DA(lpart, float, (long)B * 64); DA(ltick, unsigned, B); DA(d_pos, int32_t, 4); DA(d_lang_tokens, int32_t, 256); DA(d_lang_out, int32_t, B); DA(d_lang_probs, float, (long)B * 256);
-#undef DA
-    if (!ok) { ctx->err = "hipMalloc failed while sizing the context (out of device memory?)"; return bail(NH_ERR_NOMEM); }
-    ctx->ds.suppress = ctx->suppress;
-    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_done), sizeof(int32_t) * 128, 0) != hipSuccess) {
-        ctx->err = "hipHostMalloc failed"; return bail(NH_ERR_NOMEM);
-    }
-    {   // encoder sinusoids, recomputed in f32 exactly as candle's sinusoids() (SURVEY.md 3.3-2)
-        std::vector<float> pos(1500L * d);
-        int half = d / 2;
-        float inc = logf(10000.0f) / (float)(half - 1);
-        for (int p = 0; p < 1500; p++)
-            for (int i = 0; i < half; i++) {
-                float st = (float)p * expf((float)i * (-inc));
-                pos[(long)p * d + i] = sinf(st);
-                pos[(long)p * d + half + i] = cosf(st);
-            }
-        if (hipMemcpy(ctx->enc_pos, pos.data(), pos.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
-            ctx->err = "hipMemcpy(enc_pos) failed"; return bail(NH_ERR_HIP);
-        }
-    }
-    int rc = build_mel_tables(ctx);
-    if (rc != NH_OK) return bail(rc);
-    *out = ctx;
-    return NH_OK;
+    if (hipSetDevice(device_ordinal) != hipSuccess) { g_create_error = "hipSetDevice failed"; return NH_ERR_HIP; }
+    std::string err; int code = NH_ERR_HIP;
+    std::shared_ptr<nh_model> mdl = build_model(device_ordinal, cfg, err, code);
+    if (!mdl) { g_create_error = err; return code; }
+    return build_context(mdl, max_batch, out);
+}
+
+// A second (third ...) context on the SAME device over the SAME weights: own stream, workspaces, K/V caches, tokens and
+// decode state; the model tables are shared and reference counted (freed with the last context).
+extern "C" int nh_create_shared(nh_ctx *parent, int max_batch, nh_ctx **out) {
+    if (!parent || !out || max_batch < 1 || max_batch > 64) { g_create_error = "nh_create_shared: bad arguments (1 <= max_batch <= 64)"; return NH_ERR_INVALID; }
+    return build_context(parent->mdl, max_batch, out);
 }
 
 // ---- weight loading ----------------------------------------------------------------------------------
@@ -353,7 +436,8 @@ extern "C" int nh_load_tensor(nh_ctx *ctx, const char *name_c, int dtype, const 
     hipSetDevice(ctx->dev);
     const std::string name(name_c);
     if (name == "model.encoder.embed_positions.weight" || name == "proj_out.weight") return NH_OK;  // not read by candle
-    if (!ctx->expected.count(name)) return ctx->fail(NH_ERR_INVALID, "nh_load_tensor: unknown tensor name " + name);
+    if (!ctx->mdl->expected.count(name)) return ctx->fail(NH_ERR_INVALID, "nh_load_tensor: unknown tensor name " + name);
+    ensure_views(ctx);
     size_t n = 1;
     for (int i = 0; i < ndim; i++) n *= (size_t)shape[i];
     const int d = ctx->c.d_model;
@@ -420,7 +504,10 @@ extern "C" int nh_load_tensor(nh_ctx *ctx, const char *name_c, int dtype, const 
             else return ctx->fail(NH_ERR_INVALID, "nh_load_tensor: unhandled tensor " + name);
         }
     }
-    if (rc == NH_OK) { ctx->loaded.insert(name); ctx->dec_tiled_valid = false; }
+    if (rc == NH_OK) {
+        std::lock_guard<std::mutex> lk(ctx->mdl->mu);
+        ctx->mdl->loaded.insert(name); ctx->mdl->dec_tiled_valid = false;
+    }
     return rc;
 }
 
@@ -428,35 +515,47 @@ extern "C" int nh_load_tensor(nh_ctx *ctx, const char *name_c, int dtype, const 
 // instruction reads 1 KiB contiguous instead of 16 row pieces of 64 B.  Done lazily before the first decoder use and
 // again after any nh_load_tensor; the row-major originals stay (embedding lookup, cross-K/V GEMM, re-loading).
 static int ensure_decoder_repack(nh_ctx *ctx) {
-    if (ctx->dec_tiled_valid) return NH_OK;
-    const int d = ctx->c.d_model, V = ctx->c.vocab_size;
-    auto one = [&](half_t *&dst, const half_t *src, int N, int K) -> bool {
-        if (!dst) dst = dalloc<half_t>(ctx, (size_t)((N + 15) / 16) * 16 * K, false);
-        if (!dst) return false;
-        launch_repack_tiles(src, dst, N, K, ctx->sd);
-        return true;
-    };
-    bool ok = one(ctx->tok_emb_t, ctx->tok_emb, V, d);
-    for (auto &L : ctx->dec) {
-        ok = ok && one(L.qkv.wt, L.qkv.w, 3 * d, d) && one(L.o.wt, L.o.w, d, d) && one(L.cq.wt, L.cq.w, d, d) &&
-             one(L.co.wt, L.co.w, d, d) && one(L.fc1.wt, L.fc1.w, 4 * d, d) && one(L.fc2.wt, L.fc2.w, d, 4 * d);
+    nh_model &m = *ctx->mdl;
+    {
+        std::lock_guard<std::mutex> lk(m.mu);   // contexts that share the model may get here together: one of them repacks
+        if (!m.dec_tiled_valid) {
+            const int d = ctx->c.d_model, V = ctx->c.vocab_size;
+            bool moved = false;
+            auto one = [&](half_t *&dst, const half_t *src, int N, int K) -> bool {
+                if (!dst) { dst = dalloc_into<half_t>(m.allocs, (size_t)((N + 15) / 16) * 16 * K, false); moved = true; }
+                if (!dst) return false;
+                launch_repack_tiles(src, dst, N, K, ctx->sd);
+                return true;
+            };
+            bool ok = one(m.tok_emb_t, m.tok_emb, V, d);
+            for (auto &L : m.dec) {
+                ok = ok && one(L.qkv.wt, L.qkv.w, 3 * d, d) && one(L.o.wt, L.o.w, d, d) && one(L.cq.wt, L.cq.w, d, d) &&
+                     one(L.co.wt, L.co.w, d, d) && one(L.fc1.wt, L.fc1.w, 4 * d, d) && one(L.fc2.wt, L.fc2.w, d, 4 * d);
+            }
+            if (!ok) return ctx->fail(NH_ERR_NOMEM, "hipMalloc(tile-major decoder weights)");
+            HIPCHK(hipStreamSynchronize(ctx->sd));
+            HIPCHK(hipGetLastError());
+            m.dec_tiled_valid = true;
+            if (moved) m.version++;
+        }
     }
-    if (!ok) return ctx->fail(NH_ERR_NOMEM, "hipMalloc(tile-major decoder weights)");
-    HIPCHK(hipStreamSynchronize(ctx->sd));
-    HIPCHK(hipGetLastError());
-    ctx->dec_tiled_valid = true;
+    ensure_views(ctx);
     return NH_OK;
 }
 
 extern "C" int nh_missing_tensors(const nh_ctx *ctx) {
-    return ctx ? (int)(ctx->expected.size() - ctx->loaded.size()) : -1;
+    if (!ctx) return -1;
+    std::lock_guard<std::mutex> lk(ctx->mdl->mu);
+    return (int)(ctx->mdl->expected.size() - ctx->mdl->loaded.size());
 }
 
 extern "C" int nh_set_mel_filters(nh_ctx *ctx, const float *filters, int n_mel) {
     if (!ctx || !filters) return NH_ERR_INVALID;
     if (n_mel != ctx->c.num_mel_bins) return ctx->fail(NH_ERR_INVALID, "Unexpected number of mel bins (num_mel_bins), got: " + std::to_string(n_mel));
     hipSetDevice(ctx->dev);
-    float *df = dalloc<float>(ctx, (size_t)n_mel * 201);
+    nh_model &m = *ctx->mdl;
+    std::lock_guard<std::mutex> lk(m.mu);
+    float *df = dalloc_into<float>(m.allocs, (size_t)n_mel * 201);
     if (!df) return ctx->fail(NH_ERR_NOMEM, "hipMalloc(mel filters)");
     HIPCHK(hipMemcpy(df, filters, (size_t)n_mel * 201 * 4, hipMemcpyHostToDevice));
     std::vector<int32_t> grp(2 * n_mel);
@@ -470,9 +569,9 @@ extern "C" int nh_set_mel_filters(nh_ctx *ctx, const float *filters, int n_mel) 
         if (g0 > g1) g0 = g1 = 0;
         grp[2 * m] = g0; grp[2 * m + 1] = g1;
     }
-    HIPCHK(hipMemcpy(ctx->mel_grp, grp.data(), grp.size() * 4, hipMemcpyHostToDevice));
-    ctx->mt.filters = df;
-    ctx->have_filters = true;
+    HIPCHK(hipMemcpy(m.mel_grp, grp.data(), grp.size() * 4, hipMemcpyHostToDevice));
+    m.mt.filters = df;
+    m.have_filters = true;
     return NH_OK;
 }
 
@@ -520,13 +619,13 @@ static int prepare_batch(nh_ctx *ctx, const int32_t *n_samples, int batch) {
 }
 
 static int run_logmel(nh_ctx *ctx, const float *pcm_dev, const int32_t *n_samples, int64_t stride, int batch) {
-    if (!ctx->have_filters) return ctx->fail(NH_ERR_STATE, "nh_logmel: mel filters not set");
+    if (!ctx->mdl->have_filters) return ctx->fail(NH_ERR_STATE, "nh_logmel: mel filters not set");
     int rc = prepare_batch(ctx, n_samples, batch);
     if (rc) return rc;
     HIPCHK(hipMemcpyAsync(ctx->nsamp, n_samples, sizeof(int32_t) * batch, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->st));
     HIPCHK(hipMemsetAsync(ctx->chunk_max, 0, sizeof(unsigned) * batch, ctx->st));
-    launch_logmel_grp(pcm_dev, ctx->nsamp, stride, ctx->mt, ctx->mel_grp, ctx->c.num_mel_bins, ctx->frames, ctx->mel32,
+    launch_logmel_grp(pcm_dev, ctx->nsamp, stride, ctx->mdl->mt, ctx->mdl->mel_grp, ctx->c.num_mel_bins, ctx->frames, ctx->mel32,
                       ctx->chunk_max, batch, ctx->st);
     launch_mel_finish_ex(ctx->mel32, ctx->chunk_max, ctx->mel_img, batch, ctx->c.num_mel_bins, ctx->frames, 1, ctx->st);
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->st));
@@ -647,6 +746,7 @@ extern "C" int nh_encode(nh_ctx *ctx) {
     if (!ctx->have_mel) return ctx->fail(NH_ERR_STATE, "nh_encode: call nh_logmel first");
     if (nh_missing_tensors(ctx) != 0) return ctx->fail(NH_ERR_STATE, "nh_encode: " + std::to_string(nh_missing_tensors(ctx)) + " tensors not loaded");
     hipSetDevice(ctx->dev);
+    ensure_views(ctx);
     const int d = ctx->c.d_model, B = ctx->cur_batch, F = ctx->frames, S = ctx->S, H = ctx->c.encoder_attention_heads;
     const int M = B * S;
     ctx->gemm_ev_used = 0; ctx->gemm_flops_acc = 0.0;
@@ -982,8 +1082,7 @@ extern "C" int nh_reset(nh_ctx *ctx) {  // Type::reset_kv_cache (model.rs:485-49
 extern "C" int nh_synchronize(nh_ctx *ctx) {
     if (!ctx) return NH_ERR_INVALID;
     hipSetDevice(ctx->dev);
-    HIPCHK(hipStreamSynchronize(ctx->st));
-    HIPCHK(hipStreamSynchronize(ctx->sd));
+    HIPCHK(hipStreamSynchronize(ctx->st));   // sd is the same stream
     return NH_OK;
 }
 

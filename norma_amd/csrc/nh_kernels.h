@@ -40,6 +40,7 @@ struct GemmParams {
     int S, H;                                   // rows per clip / heads (V^T and conv2 epilogues)
     const float *pos;                           // conv2: positional embedding [S][N]
     int cus;                                    // workgroups of the persistent grid; 0 = one per CU (tools/cumask runs it on CU-masked streams)
+    unsigned long long *dbg;                    // -DG2_STAMPS diagnostic builds only (tools/gstamps): per-workgroup time stamps; else unused
 };
 void launch_gemm(const GemmParams &p, hipStream_t st);
 void launch_gemm_128(const GemmParams &p, hipStream_t st);  // always the 128 x 128 kernel

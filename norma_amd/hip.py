@@ -81,6 +81,7 @@ def load_library() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     vp, fp, ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32)
     L.nh_create.argtypes = [C.c_int, C.POINTER(NhConfig), C.c_int, C.POINTER(vp)]
+    L.nh_create_shared.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.nh_destroy.argtypes = [vp]
     L.nh_destroy.restype = None
     L.nh_last_error.argtypes = [vp]
@@ -132,15 +133,20 @@ class HipWhisper:
     """One Whisper model resident on one MI355X (one `nh_ctx`).  Not thread-safe, like the
     reference's `Model: Send` (one transcriber thread calls it, `src/lib.rs:462-464`)."""
 
-    def __init__(self, cfg: Config, device: int = 0, max_batch: int = 1):
+    def __init__(self, cfg: Config, device: int = 0, max_batch: int = 1, share_with: "Optional[HipWhisper]" = None):
+        """share_with: another HipWhisper on the same device whose WEIGHTS (and mel filters) this context uses
+        (nh_create_shared); tokens, streams, workspaces and K/V caches are its own."""
         self.L = load_library()
         self.cfg = cfg
         self.max_batch = max_batch
-        c = NhConfig(cfg.num_mel_bins, cfg.max_source_positions, cfg.d_model, cfg.encoder_attention_heads,
-                     cfg.encoder_layers, cfg.vocab_size, cfg.max_target_positions,
-                     cfg.decoder_attention_heads, cfg.decoder_layers)
         h = C.c_void_p()
-        rc = self.L.nh_create(device, C.byref(c), max_batch, C.byref(h))
+        if share_with is not None:
+            rc = self.L.nh_create_shared(share_with._h, max_batch, C.byref(h))
+        else:
+            c = NhConfig(cfg.num_mel_bins, cfg.max_source_positions, cfg.d_model, cfg.encoder_attention_heads,
+                         cfg.encoder_layers, cfg.vocab_size, cfg.max_target_positions,
+                         cfg.decoder_attention_heads, cfg.decoder_layers)
+            rc = self.L.nh_create(device, C.byref(c), max_batch, C.byref(h))
         if rc != 0:
             raise HipError(rc, self.L.nh_last_error(None).decode())
         self._h = h

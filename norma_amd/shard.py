@@ -69,21 +69,42 @@ def unpack_results(buf: np.ndarray, ctx_len: int, count: int) -> List[dict]:
     return out
 
 
-def gather_results(local: Sequence[dict], n_chunks: int, ctx_len: int, device=None) -> List[dict]:
+def gather_results(local: Sequence[dict], n_chunks: int, ctx_len: int, device=None,
+                   assignment: Sequence[Sequence[int]] = None) -> List[dict]:
     """All ranks call this; every rank gets the results of all chunks in chunk order.
-    Requires an initialised torch.distributed process group (nccl -> pass the rank's cuda device)."""
+    Requires an initialised torch.distributed process group (nccl -> pass the rank's cuda device).
+    assignment: chunk indices per rank when the job was dealt with partition_balanced (rank r passes the results of
+    assignment[r], in that order); None = the contiguous partition()."""
     import torch
     import torch.distributed as dist
     world, rank = dist.get_world_size(), dist.get_rank()
-    parts = partition(n_chunks, world)
-    slots = max(c for _, c in parts)
-    assert len(local) == parts[rank][1]
+    counts = [c for _, c in partition(n_chunks, world)] if assignment is None else [len(a) for a in assignment]
+    slots = max(max(counts), 1)
+    assert len(local) == counts[rank]
     mine = torch.from_numpy(pack_results(local, ctx_len, slots))
     if device is not None:
         mine = mine.to(device)
     bufs = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(bufs, mine)
     out: List[dict] = []
-    for k, (_, c) in enumerate(parts):
+    for k, c in enumerate(counts):
         out.extend(unpack_results(bufs[k].cpu().numpy(), ctx_len, c))
+    if assignment is not None:
+        inv = scatter_order(assignment)
+        out = [out[inv[i]] for i in range(n_chunks)]
     return out
+
+
+def length_buckets(indices: Sequence[int], costs: Sequence[float], batch: int) -> List[List[int]]:
+    """One rank's chunks cut into batches of <= `batch` with similar cost: a batch decodes until its LONGEST sequence ends
+    (the reference's loop ends per sequence at eot, model.rs:317; in a batch the finished rows wait), so bucketing by the
+    measured (or estimated) decode length is what keeps the wasted row-steps small.  Shortest first."""
+    order = sorted(indices, key=lambda i: (costs[i], i))
+    return [order[i:i + batch] for i in range(0, len(order), batch)]
+
+
+def wasted_row_steps(batches: Sequence[Sequence[int]], steps: Sequence[int]) -> Tuple[int, int]:
+    """(row-steps run, row-steps needed) when every batch runs max(steps) of its members."""
+    run = sum(len(b) * max(steps[i] for i in b) for b in batches if b)
+    need = sum(steps[i] for b in batches for i in b)
+    return run, need

@@ -63,3 +63,15 @@ def test_struct_layouts_match_the_header():
     assert C.sizeof(hip.NhTokens) == 8 * 4
     assert C.sizeof(hip.NhDecodeResult) == 24
     assert C.sizeof(hip.NhTimings) == 40
+
+
+def test_integration_md_binds_every_declared_function():
+    """INTEGRATION.md's `norma-hip-sys` block is the binding a maintainer would paste: it must declare every function of
+    include/norma_hip.h (17 of 30 were listed, the batched entry point among the missing)."""
+    import re
+    with open(os.path.join(common.ROOT, "INTEGRATION.md")) as f:
+        md = f.read()
+    block = md[md.index('extern "C" {'):]
+    block = block[:block.index("```")]
+    bound = set(re.findall(r"pub fn (nh_[a-z_0-9]+)", block))
+    assert bound == set(hip.declared_symbols()), (set(hip.declared_symbols()) - bound, bound - set(hip.declared_symbols()))

@@ -53,3 +53,27 @@ def test_weak_default_workload_reports_the_ranks_that_ran():
 def test_gpus_flag_must_agree_with_an_external_launcher():
     p = _run(["--gpus", "2", "--dry-run"], env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and "WORLD_SIZE=1" in (p.stderr + p.stdout)
+
+
+def test_variable_length_job_is_dealt_by_measured_length_and_gathered_back_in_chunk_order():
+    """workload varlen, rehearsed: placeholder decode lengths, the real shard.partition_balanced (longest-processing-time
+    deal; the reference's loop ends per sequence at eot, model.rs:317, so chunks are NOT equally expensive) and the real
+    gather with its chunk-order restoration, 3 gloo ranks."""
+    p = _run(["--gpus", "3", "--workload", "varlen", "--dry-run"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    j = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert j["n_gpus"] == 3 and j["gathered"] == 64 and sum(j["config"]["chunks_per_rank"]) == 64
+    assert j["gathered_third_tokens"] == [1000 + k for k in range(64)]     # chunk order restored after the balanced deal
+    bal, con = j["balanced_loads"], j["contiguous_loads"]
+    assert sum(bal) == sum(con) and max(bal) - min(bal) <= 300 and max(bal) <= max(con)
+
+
+def test_rank_share_and_length_bucket_helpers():
+    from norma_amd import shard
+    steps = [400, 30, 35, 390, 40, 380, 45, 50]
+    arrival = [[0, 1, 2, 3], [4, 5, 6, 7]]
+    buckets = shard.length_buckets(list(range(8)), steps, 4)
+    assert buckets == [[1, 2, 4, 6], [7, 5, 3, 0]]
+    run_a, need = shard.wasted_row_steps(arrival, steps)
+    run_b, need_b = shard.wasted_row_steps(buckets, steps)
+    assert need == need_b == sum(steps) and run_a == 4 * 400 + 4 * 380 and run_b == 4 * 45 + 4 * 400 and run_b < run_a
