@@ -31,7 +31,7 @@ __device__ __forceinline__ float gelu_tanh_f(float v) { return gelu_tanh_fast(v)
 
 __device__ __forceinline__ const half_t *a_row_ptr(const GemmParams &p, int m) {
     if (m >= p.M) m = p.M - 1;  // clamp: tail rows are loaded but never stored
-    int b = m / p.a_rpb, r = m - b * p.a_rpb;
+    int b = nh_div(m, p.a_rpb, p.a_magic), r = m - b * p.a_rpb;
     return p.A + (long)b * p.a_bstride + (long)r * p.lda;
 }
 
@@ -111,7 +111,7 @@ __device__ __forceinline__ void gemm_mainloop(const GemmParams &p, char *smem, i
 }
 
 __device__ __forceinline__ long out_row(const GemmParams &p, int m) {
-    int b = m / p.o_rpb, r = m - b * p.o_rpb;
+    int b = nh_div(m, p.o_rpb, p.o_magic), r = m - b * p.o_rpb;
     return (long)b * p.o_bstride + r + p.o_off;
 }
 
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
             for (int j = 0; j < 4; j++) {
                 int m = m0 + wm * 64 + 16 * j + 4 * fq;
                 if (m >= p.M) continue;
-                int b = m / p.S, s = m - b * p.S;
+                int b = nh_div(m, p.S, p.s_magic), s = m - b * p.S;
                 half_t *row = dst + ((long)(b * p.H + h) * NH_DH + dh) * NH_SP;
                 if (s + 3 < p.S && m + 3 < p.M) {
                     half4 v = {(half_t)(acc[i][j][0] + bv), (half_t)(acc[i][j][1] + bv),
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
                     for (int r = 0; r < 4; r++) {
                         int mm = m + r;
                         if (mm >= p.M) break;
-                        int bb = mm / p.S, ss = mm - bb * p.S;
+                        int bb = nh_div(mm, p.S, p.s_magic), ss = mm - bb * p.S;
                         dst[((long)(bb * p.H + h) * NH_DH + dh) * NH_SP + ss] = (half_t)(acc[i][j][r] + bv);
                     }
                 }
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
                     v[2] = gelu_tanh_f(v[2]); v[3] = gelu_tanh_f(v[3]);
                 }
                 const int nl = n - seg * p.seg_n;
-                half_t *dst = p.head_major ? obase + (((long)(m / p.S) * p.H + (nl >> 6)) * p.S + m % p.S) * NH_DH + (nl & 63)
+                half_t *dst = p.head_major ? obase + (((long)nh_div(m, p.S, p.s_magic) * p.H + (nl >> 6)) * p.S + (m - nh_div(m, p.S, p.s_magic) * p.S)) * NH_DH + (nl & 63)
                                            : obase + out_row(p, m) * p.ldo + nl;
                 half4 hv = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
                 *reinterpret_cast<half4 *>(dst) = hv;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
                 f32x4 x = *reinterpret_cast<const f32x4 *>(dst);
                 *reinterpret_cast<f32x4 *>(dst) = x + v;
             } else {  // EPI_CONV2_F32
-                int s = m % p.S;
+                int s = m - nh_div(m, p.S, p.s_magic) * p.S;
                 f32x4 pe = *reinterpret_cast<const f32x4 *>(p.pos + (long)s * p.N + n);
                 f32x4 o = {gelu_tanh_f(v[0]) + pe[0], gelu_tanh_f(v[1]) + pe[1], gelu_tanh_f(v[2]) + pe[2],
                            gelu_tanh_f(v[3]) + pe[3]};
@@ -257,7 +257,12 @@ struct PPSource { unsigned ag[2][2], wg[2][2]; };  // [h][i]: 32-bit element off
 // staging map: half-tile slot s = tid + 512 i (i = 0, 1): LDS row l = s >> 3 = (tid >> 3) + 64 i, chunk' = tid & 7,
 // source chunk = chunk' ^ ((l >> 1) & 7) (64 i leaves the swizzle unchanged)
 __device__ __forceinline__ PPSource pp_source(const GemmParams &p, int m0, int n0) {
-    const int tid = threadIdx.x, lrow = tid >> 3;
+    // the lane constants below are recomputed for every tile on purpose: hoisted out of the tile loop they do not fit beside
+    // 128 accumulators + 64 fragment registers, get spilled, and their reloads (scratch loads count in vmcnt) make hipcc
+    // drain vmcnt(0) in front of the prologue DMAs
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lrow = tid >> 3;
     const int csrc = ((tid & 7) ^ ((lrow >> 1) & 7)) * 8;
     PPSource sg;
 #pragma unroll
@@ -416,32 +421,37 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmParams p) {
     for (;;) {
         const int m0 = tm * G2_BM, n0 = tn * G2_BN;
         f32x4 acc[8][4];
-        if (EPI == EPI_RESID_F32) {
-            // x += A.W + bias: the residual tile and the bias are the INITIAL accumulator, fetched while the prologue
-            // half-tiles are in flight, so the epilogue is store-only
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int n = n0 + wn * 64 + 16 * j + 4 * fq;
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) bv = *reinterpret_cast<const f32x4 *>(p.bias + n);
+        for (int i = 0; i < 8; i++)
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    int m = m0 + wm * 128 + 16 * i + fr;
-                    if (m >= p.M) m = p.M - 1;
-                    acc[i][j] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const float *>(p.out[0]) + (long)m * p.ldo + n) + bv;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; i++)
-#pragma unroll
-                for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
+            for (int j = 0; j < 4; j++) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         const int seg = (EPI == EPI_F16 || EPI == EPI_GELU_F16) ? n0 / p.seg_n : 0;
         const bool vt = (EPI == EPI_F16 && seg == p.vt_seg);
         if (vt) pp_main<false>(p, smem, wbase, sg, acc);
         else pp_main<true>(p, smem, wbase, sg, acc);
 
+#ifdef G2_STAMPS
+        if (threadIdx.x == 0 && p.dbg) p.dbg[blockIdx.x * 32 + 3] += __builtin_amdgcn_s_memrealtime() - (stamp_n ? p.dbg[blockIdx.x * 32 + 4 + stamp_n - 1] : p.dbg[blockIdx.x * 32]);   // time from tile start to the end of its main loop, summed
+#endif
+        // EPI_RESID_F32: residual values of four 16-row blocks (64 VGPRs: the fragment registers are dead here), fetched through a
+        // buffer descriptor over x[M][ldo]: rows >= M of the last, partial M-panel fall outside it, so their loads return 0 and
+        // their stores are dropped by the hardware -- no per-row guard (a guard makes hipcc wrap each row block's stores in an
+        // exec-masked region behind s_waitcnt vmcnt(0), and on gfx950 vmcnt counts STORES too: the row blocks would go out one
+        // store round trip after the other)
+        f32x4 rs[4][4];
+        __amdgpu_buffer_rsrc_t xrs;
+        unsigned xoff = 0;
+        if (EPI == EPI_RESID_F32) {
+            xrs = __builtin_amdgcn_make_buffer_rsrc(p.out[0], 0, (int)((long)p.M * p.ldo * 4), 0x00020000);
+            int ln = threadIdx.x;
+            asm volatile("" : "+v"(ln));   // recomputed per tile (a hoisted lane constant is spilled, and its reload drains vmcnt: pp_source)
+            xoff = (unsigned)(((long)(m0 + (ln >> 8) * 128 + (ln & 15)) * p.ldo + n0 + ((ln >> 6) & 3) * 64 + 4 * ((ln >> 4) & 3)) * 4);   // row block i at + 64 i ldo, piece j at + 64 j
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    rs[ii][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff + (unsigned)(64 * ii * p.ldo + 64 * j), 0, 0));
+        }
         // every wave is through its last phase: the ring is free.  Start the next tile's first fetches now.
         const int nvb = vb + gridDim.x;
         const bool more = nvb < nwg;
@@ -475,7 +485,7 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmParams p) {
                         const int n = n0 + wn * 64 + 16 * j + nrow, nl = n - seg * p.seg_n, h = nl >> 6, dh = nl & 63;
                         const int m = m0 + wm * 128 + 64 * hh + mc;
                         if (m >= p.M) continue;
-                        const int b = m / p.S, ss = m - b * p.S;
+                        const int b = nh_div(m, p.S, p.s_magic), ss = m - b * p.S;
                         if (ss + 7 < p.S && m + 7 < p.M) {
                             half8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                             *reinterpret_cast<half8 *>(dst + ((long)(b * p.H + h) * NH_DH + dh) * NH_SP + ss) = o;
@@ -483,7 +493,7 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmParams p) {
                             for (int r = 0; r < 8; r++) {
                                 const int mm = m + r;
                                 if (mm >= p.M) break;
-                                const int bb = mm / p.S, s2 = mm - bb * p.S;
+                                const int bb = nh_div(mm, p.S, p.s_magic), s2 = mm - bb * p.S;
                                 dst[((long)(bb * p.H + h) * NH_DH + dh) * NH_SP + s2] = r < 4 ? lo[r] : hi[r - 4];
                             }
                         }
@@ -521,40 +531,60 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmParams p) {
                     if (m < p.M) {
                         half8 o = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                         // head-major: the wave's 64 columns are one head (seg_n and the tile base are multiples of 64)
-                        half_t *dst = p.head_major ? ob + (((long)(m / p.S) * p.H + (ncol >> 6)) * p.S + m % p.S) * NH_DH + (lane & 7) * 8
+                        half_t *dst = p.head_major ? ob + (((long)nh_div(m, p.S, p.s_magic) * p.H + (ncol >> 6)) * p.S + (m - nh_div(m, p.S, p.s_magic) * p.S)) * NH_DH + (lane & 7) * 8
                                                    : ob + out_row(p, m) * p.ldo + ncol;
                         *reinterpret_cast<half8 *>(dst) = o;
                     }
                 }
             }
+        } else if (EPI == EPI_RESID_F32) {
+            // x[m][n] += acc + bias.  r01/r02 took the residual tile as the INITIAL accumulator: 32 loads per lane queued behind the
+            // twelve prologue DMAs and waited for before the first MFMA -- 12.8 us of every 57 us out-proj tile with the matrix
+            // pipe idle (tools/gstamps, profiles/r03_gstamps.txt).  Now the tile is fetched here, after the main loop, 16 loads per
+            // lane at a time into the registers the fragments no longer need (the first sixteen were issued BEFORE the next tile's
+            // prologue DMAs, see above), added in the reference's order x + (A.W + bias), and stored: the residual traffic runs
+            // under the next tile's first fetches instead of in front of this tile's first MFMA.
+            f32x4 bv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bv[j] = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 64 + 16 * j + 4 * fq);
+            }
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)   // the four 64-byte pieces of one 256-byte row segment back to back
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs[ii][j] + (acc[ii][j] + bv[j])), xrs, xoff + (unsigned)(64 * ii * p.ldo + 64 * j), 0, 0);
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    rs[ii][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xoff + (unsigned)(64 * (4 + ii) * p.ldo + 64 * j), 0, 0));
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, rs[ii][j] + (acc[4 + ii][j] + bv[j])), xrs, xoff + (unsigned)(64 * (4 + ii) * p.ldo + 64 * j), 0, 0);
         } else {
-            // f32 outputs straight from the accumulators: lane holds columns n = nb + 4 fq + r (16 B) of row m = mb + fr
+            // EPI_CONV2_F32: f32 outputs straight from the accumulators: lane holds columns n = nb + 4 fq + r (16 B) of row m = mb + fr
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int n = n0 + wn * 64 + 16 * j + 4 * fq;
                 f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (EPI == EPI_CONV2_F32 && p.bias) bv = *reinterpret_cast<const f32x4 *>(p.bias + n);
+                if (p.bias) bv = *reinterpret_cast<const f32x4 *>(p.bias + n);
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
                     const int m = m0 + wm * 128 + 16 * i + fr;
                     if (m >= p.M) continue;
-                    if (EPI == EPI_RESID_F32) {
-                        // acc already holds x + bias + A.W (the accumulator was initialised with the residual tile)
-                        *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out[0]) + (long)m * p.ldo + n) = acc[i][j];
-                    } else {  // EPI_CONV2_F32
-                        const f32x4 v = acc[i][j] + bv;
-                        const int s = m % p.S;
-                        const f32x4 pe = *reinterpret_cast<const f32x4 *>(p.pos + (long)s * p.N + n);
-                        f32x4 o = {gelu_tanh_f(v[0]) + pe[0], gelu_tanh_f(v[1]) + pe[1], gelu_tanh_f(v[2]) + pe[2],
-                                   gelu_tanh_f(v[3]) + pe[3]};
-                        *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out[0]) + (long)m * p.ldo + n) = o;
-                    }
+                    const f32x4 v = acc[i][j] + bv;
+                    const int s = m - nh_div(m, p.S, p.s_magic) * p.S;
+                    const f32x4 pe = *reinterpret_cast<const f32x4 *>(p.pos + (long)s * p.N + n);
+                    f32x4 o = {gelu_tanh_f(v[0]) + pe[0], gelu_tanh_f(v[1]) + pe[1], gelu_tanh_f(v[2]) + pe[2],
+                               gelu_tanh_f(v[3]) + pe[3]};
+                    *reinterpret_cast<f32x4 *>(reinterpret_cast<float *>(p.out[0]) + (long)m * p.ldo + n) = o;
                 }
             }
         }
-#ifdef G2_STAMPS
-        if (threadIdx.x == 0 && p.dbg && stamp_n < 28) { p.dbg[blockIdx.x * 32 + 4 + stamp_n] = __builtin_amdgcn_s_memrealtime(); stamp_n++; p.dbg[blockIdx.x * 32 + 2] = stamp_n; }
-#endif
         if (!more) break;
         vb = nvb;
     }
@@ -573,7 +603,15 @@ static int device_cu_count() {
     return n;
 }
 
-void launch_gemm(const GemmParams &p, hipStream_t st) {
+static GemmParams with_magics(const GemmParams &p_in) {
+    GemmParams p = p_in;
+    const long max_m = (long)p.M - 1;     // the largest row index a kernel divides (tail rows are clamped or skipped first)
+    p.a_magic = nh_magic(p.a_rpb, max_m); p.o_magic = nh_magic(p.o_rpb, max_m); p.s_magic = nh_magic(p.S, max_m);
+    return p;
+}
+
+void launch_gemm(const GemmParams &p_in, hipStream_t st) {
+    const GemmParams p = with_magics(p_in);
     const bool seg_ok = (p.epi != EPI_F16 && p.epi != EPI_GELU_F16) || (p.seg_n % G2_BN == 0);
     if (p.N % G2_BN == 0 && p.K % 128 == 0 && seg_ok && p.M >= G2_BM) {
         const int nwg = (p.N / G2_BN) * ((p.M + G2_BM - 1) / G2_BM);
@@ -592,7 +630,8 @@ void launch_gemm(const GemmParams &p, hipStream_t st) {
 }
 
 // the 128 x 128 kernel on any supported shape (N % 128 == 0, K % 64 == 0); also the reference of tools/gemm_check
-void launch_gemm_128(const GemmParams &p, hipStream_t st) {
+void launch_gemm_128(const GemmParams &p_in, hipStream_t st) {
+    const GemmParams p = with_magics(p_in);
     int ntn = p.N / BN, ntm = (p.M + BM - 1) / BM;
     hipLaunchKernelGGL(gemm_f16_kernel, dim3(ntn * ntm), dim3(256), 0, st, p);
 }

@@ -41,7 +41,25 @@ struct GemmParams {
     const float *pos;                           // conv2: positional embedding [S][N]
     int cus;                                    // workgroups of the persistent grid; 0 = one per CU (tools/cumask runs it on CU-masked streams)
     unsigned long long *dbg;                    // -DG2_STAMPS diagnostic builds only (tools/gstamps): per-workgroup time stamps; else unused
+    // filled in by launch_gemm: multipliers for the kernels' integer divisions by a_rpb, o_rpb and S (nh_magic / nh_div below)
+    unsigned a_magic, o_magic, s_magic;
 };
+// m / d for 0 <= m <= max_m as one multiply-high: magic = ceil(2^32 / d), exact while m * d < 2^32.  magic == 0 encodes
+// "d > every m" (quotient 0: a GEMM whose rows are one batch), magic == ~0u "outside the exact range: divide" (no shape of
+// this library: d is rows per clip, <= 3000).  The kernels divide row indices by run-time constants (rows per clip, S);
+// hipcc's own expansion computes the reciprocal per lane with v_rcp_iflag and keeps it live across the tile loop, where it
+// does not fit beside 128 accumulators + 64 fragment registers: it is spilled, and on gfx950 the reload (a scratch load,
+// counted in vmcnt) drains the LDS-DMA pipeline in front of every tile's first fetches.
+static inline unsigned nh_magic(int d, long max_m) {
+    if (d <= 0 || (long)d > max_m) return 0u;
+    if ((unsigned long long)max_m * (unsigned long long)d >= 0x100000000ull) return ~0u;
+    return (unsigned)((0x100000000ull + (unsigned)d - 1) / (unsigned)d);
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ int nh_div(int m, int d, unsigned magic) {
+    return magic == 0u ? 0 : magic == ~0u ? m / d : (int)__umulhi((unsigned)m, magic);
+}
+#endif
 void launch_gemm(const GemmParams &p, hipStream_t st);
 void launch_gemm_128(const GemmParams &p, hipStream_t st);  // always the 128 x 128 kernel
 

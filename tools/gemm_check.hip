@@ -34,7 +34,8 @@ int main(int argc, char **argv) {
     hipStream_t st; CK(hipStreamCreate(&st));
     struct Shape { int M, N, K, epi; } shapes[] = {{3000, 256, 128, EPI_F16}, {3000, 512, 256, EPI_F16}, {6000, 1280, 1280, EPI_F16},
                                                    {48000, 1280, 1280, EPI_GELU_F16}, {24000, 5120, 1280, EPI_GELU_F16}, {12345, 1280, 5120, EPI_F16},
-                                                   {48000, 1280, 3840, EPI_F16}, {777, 256, 384, EPI_F16}};
+                                                   {48000, 1280, 3840, EPI_F16}, {777, 256, 384, EPI_F16},
+                                                   {96000, 256, 256, EPI_F16} /* M * M >= 2^32: the row-index divisions' magic multipliers (nh_magic) */};
     const size_t maxA = (size_t)48000 * 5120, maxW = (size_t)5120 * 5120, maxO = (size_t)48000 * 5120;
     half_t *A, *W, *O1, *O2; float *bias; unsigned long long *nd;
     CK(hipMalloc(&A, maxA * 2)); CK(hipMalloc(&W, maxW * 2)); CK(hipMalloc(&O1, maxO * 2)); CK(hipMalloc(&O2, maxO * 2));

@@ -21,7 +21,7 @@ int main(int argc, char **argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 48000;
     struct Shape { int N, K, epi; const char *name; };
     Shape shapes[] = {{1280, 1280, EPI_RESID_F32, "out-proj"}, {3840, 1280, EPI_F16, "qkv"}, {5120, 1280, EPI_GELU_F16, "fc1"},
-                      {1280, 5120, EPI_RESID_F32, "fc2"}};
+                      {1280, 5120, EPI_RESID_F32, "fc2"}, {2560, 1280, EPI_F16, "cross-kv"}};
     half_t *A, *W; float *X, *bias, *pos; half_t *O0, *O1, *O2; unsigned long long *dbg;
     CK(hipMalloc(&A, (size_t)M * 5120 * 2)); CK(hipMalloc(&W, (size_t)5120 * 5120 * 2)); CK(hipMalloc(&X, (size_t)M * 1280 * 4));
     CK(hipMalloc(&bias, 5120 * 4)); CK(hipMalloc(&pos, (size_t)1500 * 1280 * 4)); CK(hipMalloc(&dbg, 256 * 32 * 8));
@@ -34,7 +34,7 @@ int main(int argc, char **argv) {
         GemmParams p{};
         p.A = A; p.lda = s.K; p.a_rpb = M; p.W = W; p.bias = bias; p.M = M; p.N = s.N; p.K = s.K; p.epi = s.epi;
         p.out[0] = (s.epi == EPI_RESID_F32) ? (void *)X : (void *)O0; p.out[1] = O1; p.out[2] = O2;
-        p.seg_n = s.N == 3840 ? 1280 : s.N; p.ldo = s.epi == EPI_RESID_F32 ? 1280 : p.seg_n;
+        p.seg_n = (s.N == 3840 || s.N == 2560) ? 1280 : s.N; p.head_major = s.N == 2560; p.ldo = s.epi == EPI_RESID_F32 ? 1280 : p.seg_n;
         p.o_rpb = M; p.vt_seg = s.N == 3840 ? 2 : -1; p.S = 1500; p.H = 20; p.pos = pos; p.dbg = dbg;
         for (int i = 0; i < 4; i++) launch_gemm(p, st);      // steady clocks and caches; the last launch is the one read
         CK(hipMemsetAsync(dbg, 0, 256 * 32 * 8, st));
@@ -59,6 +59,11 @@ int main(int argc, char **argv) {
                s.name, M, s.N, s.K, fin.size(), start.back(), fin.front(), fin[fin.size() / 10], fin[fin.size() / 2], fin[fin.size() * 9 / 10], fin.back(), fin.back() / fin[fin.size() / 2]);
         printf("          per XCD (mean finish us / mean tiles):");
         for (int x = 0; x < 8; x++) if (xn[x]) printf("  %d: %.1f/%.2f", x, xs[x] / xn[x], xt[x] / xn[x]);
+        {
+            double ml = 0, tot = 0; int nt = 0;
+            for (int b = 0; b < 256; b++) { const int n = (int)h[b * 32 + 2]; if (!n) continue; ml += h[b * 32 + 3] * 0.01; tot += (h[b * 32 + 4 + n - 1] - h[b * 32]) * 0.01; nt += n; }
+            printf("\n          per tile: %.1f us from tile start to the end of the main loop (acc init + K-loop), %.1f us from there to the next tile's start (prologue issue + epilogue)", ml / nt, (tot - ml) / nt);
+        }
         printf("\n          tile durations by position (median, max):");
         for (int i = 0; i < 32 && !dur[i].empty(); i++) { std::sort(dur[i].begin(), dur[i].end()); printf("  %.1f,%.1f", dur[i][dur[i].size() / 2], dur[i].back()); }
         printf("\n");
