@@ -15,10 +15,16 @@
 //    the QKV GEMM epilogue (k_gemm.hip), never transposed here.
 //  * K and V^T tiles are [64 rows][128 B] images with chunk' = chunk ^ ((row >> 1) & 7):
 //    conflict-free ds_read_b128 for both fragment shapes.
-// The q/k pre-scaling by dh^-1/4 each is folded into one exact *1/8 inside the
-// exponent.  1500 keys are not a multiple of 64: the last tile masks keys >= S; V^T pad is zero.
+// The q/k pre-scaling by dh^-1/4 each and the change of base to exp2 are carried by q itself
+// (q arrives multiplied by dh^-1/2 log2(e), GemmParams::seg0_scale).  1500 keys are not a multiple of 64: the last
+// tile masks keys >= S; V^T pad is zero.
 #include "nh_kernels.h"
 
+// tools/abench links several builds of this file in one process (A/B of kernel variants on one box): the symbol names are macros
+#ifndef ENC_ATTN_KERNEL
+#define ENC_ATTN_KERNEL enc_attn_kernel
+#define ENC_ATTN_LAUNCH launch_enc_attention
+#endif
 #define KT 64              // keys per tile
 #define QW 32              // queries per wave
 #ifndef ENC_ATTN_WAVES
@@ -31,7 +37,10 @@
 
 __device__ __forceinline__ int swap23(int x) { return (x & ~12) | ((x & 4) << 1) | ((x & 8) >> 1); }
 
-__global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(const half_t *__restrict__ q, const half_t *__restrict__ k,
+#ifndef ENC_ATTN_MINWAVES
+#define ENC_ATTN_MINWAVES 4   // two 8-wave workgroups per CU need <= 128 VGPRs
+#endif
+__global__ __launch_bounds__(NTHR, (NTHR <= 512 ? ENC_ATTN_MINWAVES : 1)) void ENC_ATTN_KERNEL(const half_t *__restrict__ q, const half_t *__restrict__ k,
                                                          long ld, const half_t *__restrict__ vt,
                                                          half_t *__restrict__ out, long ldo, int S, int H) {
     __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_B];
@@ -90,18 +99,29 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(c
     f32x16 o0, o1;
 #pragma unroll
     for (int i = 0; i < 16; i++) { o0[i] = 0.f; o1[i] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-    const float c_exp = 0.125f * 1.4426950408889634f;  // dh^-1/2 * log2(e)
+    // Softmax bookkeeping (r03).  This kernel is bound by VALU + transcendental issue, not by the matrix pipe (per 64-key tile a
+    // lane owns 32 scores: r02 spent 32 v_fma (scale, subtract the maximum) + 32 v_max + 32 v_exp + 32 v_add + 16 v_cvt_pk on
+    // them against 16 MFMAs), so the per-score VALU work is cut to exp + add + half a max3 + half a cvt:
+    //  * q arrives pre-scaled by dh^-1/2 * log2(e) (QKV GEMM epilogue, one rounding), so a score is already the exp2 argument;
+    //  * the subtraction of the reference maximum rides in the MATRIX product: one more 16-deep k-step whose key-side operand
+    //    is the constant (1, 1, 0, ...) and whose query-side operand is (hi, lo, 0, ...) with hi + lo = -m_ref split into two
+    //    fp16 (residual < 2^-22 |m_ref|): S' = K (c Q)^T - m_ref leaves the accumulator ready for v_exp_f32, for 2 MFMAs per tile;
+    //  * the reference moves only when it has to ("defer-max"): m_ref is set to the running maximum on the first tile and
+    //    afterwards only when a tile's maximum exceeds it by more than 2^8; in between p = exp2(S') may exceed 1 (<= 256: exact
+    //    power-of-two headroom in fp16 P and f32 sums), and the rescale of O and l happens in that rare branch only.
+    // Same softmax (the shift cancels in O / l); rounding differs from r02's in the last bit of p.
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const half_t one_h = hh == 0 ? (half_t)1.0f : (half_t)0.0f;
+    const half8 kx = {one_h, one_h, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};   // A operand of the extra k-step
+    half8 qx = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};   // B operand: (hi, lo, 0 ..) in the hh == 0 lanes
+    float m_ref = 0.f, l_run = 0.f;
+    const float REBASE = 8.0f;
 
-    int cur = 0;
-    for (int t = 0; t < nT; t++) {
-        const bool more = (t + 1 < nT);
-        if (more) load_tile(t + 1);
-        const char *tk = smem + cur * 2 * TILE_B, *tv = tk + TILE_B;
-        f32x16 s0, s1;
+    f32x16 s0, s1;   // scores of the tile in flight: written by qk_phase, consumed by sv_phase
+    // first half of a tile: S'^T = K (cQ)^T - m_ref (10 MFMAs)
+    auto qk_phase = [&](const char *tk) {
         {
             // the first k-step takes a literal zero accumulator (an inline constant of the MFMA, not 32 v_mov per tile)
-            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             half8 k0 = *reinterpret_cast<const half8 *>(tk + offK0);
             half8 k1 = *reinterpret_cast<const half8 *>(tk + 4096 + offK0);
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[0], zero, 0, 0, 0);
@@ -115,6 +135,11 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(c
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[ks], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[ks], s1, 0, 0, 0);
         }
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kx, qx, s0, 0, 0, 0);   // - m_ref for every key of the tile
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kx, qx, s1, 0, 0, 0);
+    };
+    // second half: mask, maximum / rare rebase, exp2, row sum, P -> fp16, O^T += V^T P^T (8 MFMAs)
+    auto sv_phase = [&](int t, const char *tv) {
         if (t * KT + KT > S) {  // last, partial tile: mask keys >= S
 #pragma unroll
             for (int i = 0; i < 16; i++) {
@@ -124,38 +149,36 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(c
                 if (key1 >= S) s1[i] = -INFINITY;
             }
         }
-        float mx = s0[0];
+        // tile maximum of S' with three-input maxima (16 instructions for 32 values), both key halves of the query
+        float mx = fmaxf(fmaxf(s0[0], s0[1]), s0[2]);
 #pragma unroll
-        for (int i = 1; i < 16; i++) mx = fmaxf(mx, s0[i]);
+        for (int i = 3; i < 15; i += 2) mx = fmaxf(fmaxf(mx, s0[i]), s0[i + 1]);
+        mx = fmaxf(fmaxf(mx, s0[15]), s1[0]);
 #pragma unroll
-        for (int i = 0; i < 16; i++) mx = fmaxf(mx, s1[i]);
+        for (int i = 1; i < 15; i += 2) mx = fmaxf(fmaxf(mx, s1[i]), s1[i + 1]);
+        mx = fmaxf(mx, s1[15]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c_exp);
-        const float mb = m_new * c_exp;
-        // exponent arguments and the row sum two values per instruction (v_pk_fma_f32 / v_pk_add_f32): this kernel is bound
-        // by VALU + transcendental issue, not by the matrix pipe (32 v_exp_f32 per tile are unavoidable, the rest is not)
-        f32x2 ps2 = {0.f, 0.f};
-        const f32x2 c2 = {c_exp, c_exp}, nmb2 = {-mb, -mb};
+        const bool reb = (t == 0) || (mx > REBASE);
+        if (__builtin_amdgcn_ballot_w64(reb) != 0) {   // rare after the first tile: move the reference of the queries that need it
+            const float dlt = reb ? mx : 0.f;          // tile 0: m_ref = the tile's maximum (any sign); later: only upwards
+            const float alpha = __builtin_amdgcn_exp2f(-dlt);
 #pragma unroll
-        for (int i = 0; i < 16; i += 2) {
-            f32x2 a = {s0[i], s0[i + 1]}, b = {s1[i], s1[i + 1]};
-            a = __builtin_elementwise_fma(a, c2, nmb2);
-            b = __builtin_elementwise_fma(b, c2, nmb2);
-            a[0] = __builtin_amdgcn_exp2f(a[0]); a[1] = __builtin_amdgcn_exp2f(a[1]);
-            b[0] = __builtin_amdgcn_exp2f(b[0]); b[1] = __builtin_amdgcn_exp2f(b[1]);
-            ps2 += a; ps2 += b;
-            s0[i] = a[0]; s0[i + 1] = a[1]; s1[i] = b[0]; s1[i + 1] = b[1];
+            for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; s0[i] -= dlt; s1[i] -= dlt; }
+            l_run *= alpha;
+            m_ref += dlt;
+            const float nm = fminf(fmaxf(-m_ref, -60000.f), 60000.f);
+            const half_t hi = (half_t)nm;
+            const half_t lo = (half_t)(nm - (float)hi);
+            qx[0] = hh == 0 ? hi : (half_t)0.f;
+            qx[1] = hh == 0 ? lo : (half_t)0.f;
         }
-        const float ps = ps2[0] + ps2[1];
-        l_run = l_run * alpha + ps;
-        m_run = m_new;
-        // the running maximum settles after the first tiles: when no query of the wave moved it, alpha is exactly 1 and the
-        // 32 rescaling multiplies (VALU is what bounds this kernel) are skipped -- bit-identical either way
-        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+        float ps = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; i++) { o0[i] *= alpha; o1[i] *= alpha; }
+        for (int i = 0; i < 16; i++) {
+            s0[i] = __builtin_amdgcn_exp2f(s0[i]); s1[i] = __builtin_amdgcn_exp2f(s1[i]);
+            ps += s0[i]; ps += s1[i];
         }
+        l_run += ps;
         // P^T fragments (B operand): k-step (blk, s2) takes accumulator registers 8 s2 .. 8 s2 + 7
         half8 p00, p01, p10, p11;
 #pragma unroll
@@ -175,6 +198,16 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(c
             v = *reinterpret_cast<const half8 *>(tv + (offV0 ^ (6 << 4)));          o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, p11, o0, 0, 0, 0);
             v = *reinterpret_cast<const half8 *>(tv + 4096 + (offV0 ^ (6 << 4)));   o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(v, p11, o1, 0, 0, 0);
         }
+    };
+    // (r03, tools/abench, one box: a schedule in which waves 4-7 run half a tile behind waves 0-3 -- two barriers per tile, one
+    // half multiplying K Q^T while the other does softmax + P V -- measured 640-670 us against 446-454 for this loop; four
+    // independent max / sum chains, v_dot2_f32_f16 row sums and s_setprio around the MFMA clusters all within +-1.5 %.)
+    int cur = 0;
+    for (int t = 0; t < nT; t++) {
+        const bool more = (t + 1 < nT);
+        if (more) load_tile(t + 1);
+        qk_phase(smem + cur * 2 * TILE_B);
+        sv_phase(t, smem + cur * 2 * TILE_B + TILE_B);
         if (more) store_tile(cur ^ 1);
         __syncthreads();
         cur ^= 1;
@@ -196,8 +229,8 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? 2 : 1)) void enc_attn_kernel(c
     }
 }
 
-void launch_enc_attention(const half_t *q, const half_t *k, long ld, const half_t *vt, half_t *out, long ldo,
+void ENC_ATTN_LAUNCH(const half_t *q, const half_t *k, long ld, const half_t *vt, half_t *out, long ldo,
                           int B, int S, int H, hipStream_t st) {
     dim3 grid((S + QB - 1) / QB, H, B);
-    hipLaunchKernelGGL(enc_attn_kernel, grid, dim3(NTHR), 0, st, q, k, ld, vt, out, ldo, S, H);
+    hipLaunchKernelGGL(ENC_ATTN_KERNEL, grid, dim3(NTHR), 0, st, q, k, ld, vt, out, ldo, S, H);
 }

@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_kernel(GemmParams p) {
             if (m >= p.M) continue;
             f32x4 v = acc[i][j] + bv;
             if (p.epi == EPI_F16 || p.epi == EPI_GELU_F16) {
+                if (p.epi == EPI_F16 && seg == 0 && p.seg0_scale != 0.f) v *= p.seg0_scale;
                 if (p.epi == EPI_GELU_F16) {
                     v[0] = gelu_tanh_f(v[0]); v[1] = gelu_tanh_f(v[1]);
                     v[2] = gelu_tanh_f(v[2]); v[3] = gelu_tanh_f(v[3]);
@@ -510,11 +511,13 @@ __global__ __launch_bounds__(512) void gemm256_f16_kernel(GemmParams p) {
                 if (p.bias) bv[j] = *reinterpret_cast<const f32x4 *>(p.bias + n0 + wn * 64 + 16 * j + 4 * fq);
             }
             const int ncol = n0 + wn * 64 - seg * p.seg_n + (lane & 7) * 8;
+            const bool q_scaled = EPI == EPI_F16 && seg == 0 && p.seg0_scale != 0.f;   // tile-uniform
 #pragma unroll
             for (int i = 0; i < 8; i++) {
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     f32x4 v = acc[i][j] + bv[j];
+                    if (EPI == EPI_F16 && q_scaled) v *= p.seg0_scale;
                     if (EPI == EPI_GELU_F16) {
                         v[0] = gelu_tanh_f(v[0]); v[1] = gelu_tanh_f(v[1]); v[2] = gelu_tanh_f(v[2]); v[3] = gelu_tanh_f(v[3]);
                     }

@@ -730,9 +730,9 @@ static void gemm_prof_end(nh_ctx *ctx, const GemmParams &p) {
 }
 
 static void gemm_plain(nh_ctx *ctx, const half_t *A, long lda, const LinW &W, int M, int N, int K, int epi, void *o0,
-                       void *o1, void *o2, int seg_n, long ldo, int vt_seg, int head_major = 0) {
+                       void *o1, void *o2, int seg_n, long ldo, int vt_seg, int head_major = 0, float seg0_scale = 0.f) {
     GemmParams p{};
-    p.head_major = head_major;
+    p.head_major = head_major; p.seg0_scale = seg0_scale;
     p.A = A; p.lda = lda; p.a_rpb = M; p.a_bstride = 0; p.W = W.w; p.bias = W.b; p.M = M; p.N = N; p.K = K; p.epi = epi;
     p.out[0] = o0; p.out[1] = o1; p.out[2] = o2; p.seg_n = seg_n; p.ldo = ldo; p.o_rpb = M; p.o_bstride = 0; p.o_off = 0;
     p.vt_seg = vt_seg; p.S = ctx->S; p.H = ctx->c.encoder_attention_heads; p.pos = nullptr;
@@ -769,7 +769,9 @@ extern "C" int nh_encode(nh_ctx *ctx) {
     }
     for (auto &L : ctx->enc) {
         launch_layernorm(ctx->x, L.ln1.w, L.ln1.b, ctx->xn, nullptr, M, d, ctx->st);
-        gemm_plain(ctx, ctx->xn, d, L.qkv, M, 3 * d, d, EPI_F16, ctx->q, ctx->k, ctx->vt, d, d, 2);
+        // q leaves the GEMM as (x W_q + b_q) * dh^-1/2 * log2(e): candle's q * dh^-1/4 and k * dh^-1/4 and the
+        // exp -> exp2 change of base, applied once in f32 before the one rounding to fp16 (k_attn_enc.hip)
+        gemm_plain(ctx, ctx->xn, d, L.qkv, M, 3 * d, d, EPI_F16, ctx->q, ctx->k, ctx->vt, d, d, 2, 0, NH_ENC_Q_SCALE);
         launch_enc_attention(ctx->q, ctx->k, d, ctx->vt, ctx->att, d, B, S, H, ctx->st);
         gemm_plain(ctx, ctx->att, d, L.o, M, d, d, EPI_RESID_F32, ctx->x, nullptr, nullptr, d, d, -1);
         launch_layernorm(ctx->x, L.ln2.w, L.ln2.b, ctx->xn, nullptr, M, d, ctx->st);

@@ -37,6 +37,8 @@ struct GemmParams {
     int vt_seg;                                 // segment written as V^T [b][h][64][SP] (or -1)
     int head_major;                             // EPI_F16: every segment is written [b][h][S][64] (clip b = m / S, 64-wide head h)
                                                 // instead of [m][seg_n]: the decoder streams cross K/V per (clip, head)
+    float seg0_scale;                           // EPI_F16: segment 0 is written as (acc + bias) * seg0_scale (0 = no scaling): the encoder's
+                                                // q carries the softmax scale dh^-1/2 * log2(e) into the attention kernel
     int S, H;                                   // rows per clip / heads (V^T and conv2 epilogues)
     const float *pos;                           // conv2: positional embedding [S][N]
     int cus;                                    // workgroups of the persistent grid; 0 = one per CU (tools/cumask runs it on CU-masked streams)
@@ -187,7 +189,9 @@ void launch_mel_finish_ex(float *mel32, const unsigned *chunk_max, half_t *img, 
                           int normalise, hipStream_t st);
 
 // ---- encoder attention ---------------------------------------------------------------------------------
-// q,k: fp16 [B*S][ld] (head h at column h*64); vt: fp16 [B][H][64][SP]; out: fp16 [B*S][ldo]
+// q,k: fp16 [B*S][ld] (head h at column h*64), q PRE-SCALED by NH_ENC_Q_SCALE (GemmParams::seg0_scale);
+// vt: fp16 [B][H][64][SP]; out: fp16 [B*S][ldo]
+#define NH_ENC_Q_SCALE (0.125f * 1.4426950408889634f)   // dh^-1/2 * log2(e), dh = 64
 void launch_enc_attention(const half_t *q, const half_t *k, long ld, const half_t *vt, half_t *out, long ldo,
                           int B, int S, int H, hipStream_t st);
 
