@@ -7,7 +7,10 @@ the host) over one batch of synthetic 30-second clips, PCM already resident in H
 Workloads (`--workload`):
   b32         (default, the headline) BASELINE.json configs[2]: distil-large-v3, fp16 storage / fp32 accumulate,
               32 clips per GPU.  N > 1: every rank runs its own 32 distinct clips -- weak scaling, no data-path
-              collective (chunks are independent).
+              collective (chunks are independent).  A step = one 32-clip batch through log-mel, encoder,
+              cross K/V and greedy decode; `--pipelines` x `--decode-groups` batches are in flight per GPU (3 x 2):
+              the encoder takes them 32 at a time, two of them share one 64-row decode loop (weights and embedding
+              streamed once per token for both), and three such pipelines overlap their decodes with each other's encoders.
   longform20  BASELINE.json configs[3]: one 10-minute clip (9 600 000 samples) = 20 chunks, split over the ranks with
               norma_amd.shard.partition (8 ranks: 3,3,3,3,2,2,2,2); every rank transcribes its chunks as one batch and
               the results are gathered on all ranks over RCCL inside the timed region -- strong scaling.
@@ -67,6 +70,11 @@ def parse_args(argv=None):
                     help="batches in flight per GPU (workload b32): each pipeline is its own context + host thread; "
                          "encoders are serialised by a host lock, the latency-bound decode of one batch runs beside the "
                          "MFMA-bound encoder of the next.  1 = one batch at a time")
+    ap.add_argument("--decode-groups", type=int, default=int(os.environ.get("NORMA_BENCH_DECODE_GROUPS", "2")),
+                    help="workload b32: encoder batches (of --batch clips each) that share ONE decode loop per pipeline "
+                         "(nh_logmel_device_rows / nh_encode_rows, then one nh_decode_greedy over all their rows): the decoder "
+                         "weights and the tied embedding are streamed once per token for all of them (default 2: +7 %% over 1 on one box, "
+                         "3 no better).  1 = every batch decodes alone (r02)")
     ap.add_argument("--no-graphs", action="store_true", help="A/B: launch every decode-step kernel eagerly (NH_OPT_DECODE_GRAPHS = 0)")
     ap.add_argument("--no-ln-fusion", action="store_true", help="A/B: stand-alone decoder LayerNorm kernels (NH_OPT_FUSE_DECODE_LAYERNORM = 0)")
     ap.add_argument("--private-weights", action="store_true",
@@ -254,11 +262,14 @@ def worker(args):
 
     t_build = time.time()
     P = max(1, args.pipelines) if job_chunks is None else 1   # the strong workloads run their job once per step
+    G = max(1, args.decode_groups) if job_chunks is None else 1   # encoder batches per joint decode
+    if B * G > 96:
+        raise SystemExit("bench.py: --batch x --decode-groups must be <= 96 rows per context")
     headline = args.workload == "b32" and args.model is None
     hms = []
     for i in range(P):
         shared = hms[0] if (i > 0 and not args.private_weights) else None   # one weight set per device (nh_create_shared)
-        h = hip.HipWhisper(cfg, device=local_rank, max_batch=max(B, 1), share_with=shared)
+        h = hip.HipWhisper(cfg, device=local_rank, max_batch=max(B * G, 1), share_with=shared)
         if shared is None:
             h.set_mel_filters(assets_io.mel_filters(cfg.num_mel_bins))
         h.set_tokens(tk, -1 if multilingual else tk.en, tk.transcribe)
@@ -315,9 +326,19 @@ def worker(args):
             return shard.gather_results(local, total_chunks, C, device=gather_dev)
         return local
 
+    def group_step(max_new, h, groups):
+        """`groups` encoder batches (B clips each) through log-mel + encoder one after the other, then ONE decode over all
+        their rows (lockstep positions): every batch is still one step of the contract."""
+        for g in range(groups):
+            with enc_lock:
+                h.logmel_device_rows(pcm_dev.data_ptr(), n_samples, synth.N_SAMPLES, g * B)
+                h.encode_rows(g * B, B)
+                h.synchronize()
+        return h.decode_greedy(max_new)[:B]
+
     def run_steps(n, max_new, P=P):
         """n steps spread round-robin over the pipelines (each pipeline runs its share sequentially)."""
-        if P == 1:
+        if P == 1 and G == 1:
             out = None
             for _ in range(n):
                 out = job_step(max_new)
@@ -325,8 +346,11 @@ def worker(args):
         last = [None] * P
 
         def worker_thread(i):
-            for _ in range(i, n, P):
-                last[i] = step(max_new, hms[i], pipelined=True)
+            mine = len(range(i, n, P))            # steps (32-clip batches) this pipeline owns
+            while mine > 0:
+                g = min(G, mine)
+                last[i] = step(max_new, hms[i], pipelined=True) if G == 1 else group_step(max_new, hms[i], g)
+                mine -= g
         ths = [threading.Thread(target=worker_thread, args=(i,)) for i in range(P)]
         for t in ths:
             t.start()
@@ -342,7 +366,7 @@ def worker(args):
             h.synchronize()
 
     hm.set_profile_gemm(True)  # two hipEventRecord per GEMM launch (~400 per step, < 0.5 % of a step)
-    res = run_steps(max(args.warmup, P if args.warmup else 0), args.max_new_tokens)
+    res = run_steps(max(args.warmup, P * G if args.warmup else 0), args.max_new_tokens)
     barrier()
     t0 = time.perf_counter()
     res = run_steps(args.steps, args.max_new_tokens)
@@ -359,7 +383,7 @@ def worker(args):
 
     extra = {}
     single_ms = dt / args.steps * 1e3     # wall time of a step with one batch on the GPU (the H2D comparison below)
-    if P > 1 and B:
+    if (P > 1 or G > 1) and B:
         # one batch at a time, untimed by the contract: the per-phase times (and their roofline fractions below) are taken
         # from this pass, where no other batch shares the GPU; with several batches in flight a phase's wall time
         # includes the kernels of the other batches interleaved with it
@@ -443,7 +467,9 @@ def worker(args):
             "value": value, "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": scaling, "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": (f"{model_name} fp16 batch={B} x 30 s clips per GPU" if job_chunks is None else
+            "config": {"workload": (f"{model_name} fp16 batch={B} x 30 s clips per GPU" +
+                                    (f" (encoder in batches of {B}; {G} such batches share one decode loop of {B * G} rows; "
+                                     f"{P} of these pipelines in flight)" if G > 1 else "") if job_chunks is None else
                                     f"{model_name} fp16, {total_chunks} x 30 s chunks of one job split over {world} GPU(s) "
                                     f"({[c for _, c in shard.partition(total_chunks, world)]}), results gathered over RCCL"
                                     + (", language detection + timestamp decoding" if multilingual else "")) +
@@ -451,7 +477,8 @@ def worker(args):
                                    ("to the 447-token cap (seed-0 random weights never emit eot)" if args.max_new_tokens == 0
                                     else f"{args.max_new_tokens} new tokens"),
                        "name": args.workload, "batch_per_gpu": B, "chunks": total_chunks, "clip_seconds": 30,
-                       "decode_tokens": n_tok, "parallelism": f"chunk-dp{world}", "batches_in_flight_per_gpu": P,
+                       "decode_tokens": n_tok, "parallelism": f"chunk-dp{world}", "batches_in_flight_per_gpu": P * G, "pipelines_per_gpu": P,
+                       "encoder_batches_per_decode": G,
                        "weight_sets_per_gpu": P if args.private_weights else 1},
             "phases_ms": {k: tm[k] for k in ("mel_ms", "encoder_ms", "cross_kv_ms", "decode_ms")} if tm else None,
             "decode_steps": tm["decode_steps"] if tm else 0,

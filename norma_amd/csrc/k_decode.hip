@@ -20,7 +20,7 @@
 __device__ __forceinline__ float gelu_tanh_d(float v) { return gelu_tanh_fast(v); }
 
 // ---------------------------------------------------------------------------------------------------
-// skinny GEMM: y[R][N] = x[R][K] . W[N][K]^T, R <= 64.  Weights are the MFMA A operand (16 rows per
+// skinny GEMM: y[R][N] = x[R][K] . W[N][K]^T, R <= 96.  Weights are the MFMA A operand (16 rows per
 // tile; each lane streams 16 B of one weight row per k-step, 4 lanes cover a 64 B run), activations
 // (L2-resident) the B operand.  Two shapes of the same kernel:
 //   KSPLIT = 2 .. 16 : one 16-row tile per workgroup, its KSPLIT waves split K, fp32 partials meet in
@@ -474,6 +474,91 @@ __global__ __launch_bounds__(512) void skinny_lds_kernel(SkinnyParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same logits kernel for 33 .. 96 rows (r03: several encoder batches decoded together, nh_encode_rows): the fp16 image of
+// all rows no longer fits the LDS (96 rows x 1280 x 2 B = 240 KB), so K is cut into PHASES of `sp` k-steps; the image of one
+// phase is staged, every wave multiplies its (<= 2) weight tiles over that k-range into accumulators it keeps across the
+// phases, barrier, next phase.  The weights are still streamed exactly once per token, and every output element is still
+// accumulated over k in ascending order in one f32 accumulator: bit-identical to skinny_lds_kernel's result for the same row.
+// Activations come as fp16 (LayerNorm as its own launch: the fused form would have to keep every row's statistics).
+// Requires the tile-major weights and at most LP_MT tiles per wave.
+// ---------------------------------------------------------------------------------------------------
+#define LP_MT 2
+template <int NCB>
+__global__ __launch_bounds__(512) void skinny_ldsp_kernel(SkinnyParams p, int sp) {
+    extern __shared__ __attribute__((aligned(16))) char xs[];  // sp * (16 NCB) * 64 bytes
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    constexpr int rows = 16 * NCB;
+    const int steps = p.K >> 5;
+    const int gw = blockIdx.x * 8 + w, nwav = gridDim.x * 8;
+    const int ntiles = (p.N + 15) >> 4;
+    const int my_tiles = gw < ntiles ? min(LP_MT, (ntiles - gw + nwav - 1) / nwav) : 0;
+    int boff[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) boff[cb] = (16 * cb + fr) * 64 + ((fq ^ ((-(fr >> 2)) & 3)) << 4);
+    f32x4 acc[LP_MT][NCB];
+#pragma unroll
+    for (int t = 0; t < LP_MT; t++)
+#pragma unroll
+        for (int cb = 0; cb < NCB; cb++) acc[t][cb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int ph0 = 0; ph0 < steps; ph0 += sp) {
+        const int nst = min(sp, steps - ph0);
+        const int ngrp = (nst + SK_U - 1) / SK_U;
+        const int G = my_tiles * ngrp;                 // (tile, k-group) pairs of this wave in this phase
+        auto issue = [&](int g, half8 (&a)[SK_U]) {    // unconditional clamped loads, all in flight together
+            const int tile = g / ngrp, s0 = ph0 + (g - tile * ngrp) * SK_U;
+            const half_t *wp = p.Wt + (long)(gw + tile * nwav) * steps * 512 + lane * 8;
+#pragma unroll
+            for (int u = 0; u < SK_U; u++) {
+                const int sc = s0 + u < steps ? s0 + u : steps - 1;
+                a[u] = __builtin_nontemporal_load(reinterpret_cast<const half8 *>(wp + (long)512 * sc));
+            }
+        };
+        half8 a0[SK_U], a1[SK_U];
+        if (G > 0) issue(0, a0);                       // in flight while the image is staged
+        __syncthreads();                               // every wave is done with the previous phase's image
+        for (int c = tid; c < nst * rows * 4; c += 512) {
+            const int q = c & 3, r = (c >> 2) % rows, st = (c >> 2) / rows;
+            const int rr = r < p.R ? r : p.R - 1;
+            const u32x4 v = *reinterpret_cast<const u32x4 *>(p.x + (long)rr * p.ldx + 32 * (ph0 + st) + 8 * q);
+            *reinterpret_cast<u32x4 *>(xs + ((long)st * rows + r) * 64 + ((q ^ ((-(r >> 2)) & 3)) << 4)) = v;
+        }
+        __syncthreads();
+        auto compute = [&](int g, const half8 (&a)[SK_U]) {
+            const int tile = g / ngrp, s0 = (g - tile * ngrp) * SK_U;   // phase-local k-step of the group's first step
+#pragma unroll
+            for (int u = 0; u < SK_U; u++) {
+                if (s0 + u < nst) {
+#pragma unroll
+                    for (int cb = 0; cb < NCB; cb++) {
+                        const half8 b = *reinterpret_cast<const half8 *>(xs + (long)(s0 + u) * rows * 64 + boff[cb]);
+                        if (tile == 0) acc[0][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b, acc[0][cb], 0, 0, 0);
+                        else acc[1][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[u], b, acc[1][cb], 0, 0, 0);
+                    }
+                }
+            }
+        };
+        for (int g = 0; g < G; g += 2) {
+            if (g + 1 < G) issue(g + 1, a1);
+            compute(g, a0);
+            if (g + 2 < G) issue(g + 2, a0);
+            if (g + 1 < G) compute(g + 1, a1);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < LP_MT; t++) {
+        if (t < my_tiles) {
+            const int n = 16 * (gw + t * nwav) + 4 * fq;
+#pragma unroll
+            for (int cb = 0; cb < NCB; cb++) {
+                const int r = 16 * cb + fr;
+                if (r < p.R) skinny_store(p, acc[t][cb], r, n);
+            }
+        }
+    }
+}
+
 // tile-major repack of a row-major [N][K] fp16 weight: out[(tile * K/32 + s) * 512 + lane * 8 + j] =
 // W[16 tile + (lane & 15)][32 s + 8 (lane >> 4) + j], rows >= N zero: the MFMA A fragment of (tile, k-step s) is 1 KiB contiguous
 __global__ __launch_bounds__(256) void repack_tiles_kernel(const half_t *__restrict__ W, half_t *__restrict__ out, int N, int K) {
@@ -505,7 +590,7 @@ static bool logits_lds_ok(int R, int N, int K) {
 }
 bool skinny_ln_supported(int R, int N, int K) {
     if ((N + 15) / 16 >= 2048) return R <= 32 && logits_lds_ok(R, N, K) && K <= 128 * LN_MAX_STEPS && K % 128 == 0;
-    return R <= 64 && ln_steps_ok(K);   // one 16-row block per workgroup: any number of row blocks
+    return R <= 96 && ln_steps_ok(K);   // one 16-row block per workgroup: any number of row blocks
 }
 
 template <int NCB, int NT>
@@ -552,7 +637,20 @@ static void launch_skinny_ncb(const SkinnyParams &p, hipStream_t st) {
                 if (dev >= 0 && dev < NH_MAX_DEVICES) attr_set[dev].store(true, std::memory_order_release);
             }
             hipLaunchKernelGGL((skinny_lds_kernel<NCB>), dim3(256), dim3(512), lds, st, p);
-        } else {
+        } else if (NCB >= 3 && p.Wt && !p.ln_x && tiles <= LP_MT * 2048) {
+            // 33 .. 96 rows: K in phases through the LDS (skinny_ldsp_kernel); as few phases as 144 KiB of LDS allow, balanced
+            const int steps = p.K >> 5, spmax = (144 * 1024) / (16 * NCB * 64);
+            const int phases = (steps + spmax - 1) / spmax, sp = (steps + phases - 1) / phases;
+            static std::atomic<bool> attr_set[NH_MAX_DEVICES];
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (dev < 0 || dev >= NH_MAX_DEVICES || !attr_set[dev].load(std::memory_order_acquire)) {
+                hipFuncSetAttribute(reinterpret_cast<const void *>(&skinny_ldsp_kernel<NCB>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+                if (dev >= 0 && dev < NH_MAX_DEVICES) attr_set[dev].store(true, std::memory_order_release);
+            }
+            hipLaunchKernelGGL((skinny_ldsp_kernel<NCB>), dim3(256), dim3(512), (size_t)sp * 16 * NCB * 64, st, p, sp);
+        } else if constexpr (NCB <= 4) {
             int waves = (tiles + 1) / 2;
             hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 1, 2>), dim3((waves + 1) / 2), dim3(128), 0, st, p);
         }
@@ -568,12 +666,14 @@ static void launch_skinny_ncb(const SkinnyParams &p, hipStream_t st) {
     // instantiation on a tiles x NCB grid -- so that a CU fetches 16 rows of activations instead of all of them
     // (skinny_gemm_kernel, rb).  Same per-row arithmetic as the NCB-block form.
     constexpr int RBN = NCB;   // row blocks when split
-    const bool split_rows = NCB > 1 && tiles * NCB <= 640 && tiles <= 160;
+    // (more than 64 rows -- several encoder batches decoded together -- always take the split form: no NCB = 5, 6 instantiation
+    // of the unsplit kernel exists, its LDS reduction buffer would not fit)
+    const bool split_rows = NCB > 4 || (NCB > 1 && tiles * NCB <= 640 && tiles <= 160);
     const dim3 grid = split_rows ? dim3(tiles, RBN) : dim3(tiles);
 #define SKG(KS, THR)                                                                                               \
     do {                                                                                                            \
         if (split_rows) hipLaunchKernelGGL((skinny_gemm_kernel<1, KS, 1>), grid, dim3(THR), 0, st, p);             \
-        else hipLaunchKernelGGL((skinny_gemm_kernel<NCB, KS, 1>), grid, dim3(THR), 0, st, p);                      \
+        else if constexpr (NCB <= 4) hipLaunchKernelGGL((skinny_gemm_kernel<NCB, KS, 1>), grid, dim3(THR), 0, st, p); \
     } while (0)
     if (p.K >= 2560 && fits(16)) SKG(16, 1024);
     else if (p.K >= 2560 && fits(8)) SKG(8, 512);
@@ -589,7 +689,9 @@ void launch_skinny(const SkinnyParams &p_in, hipStream_t st) {
     if (ncb <= 1) launch_skinny_ncb<1>(p, st);
     else if (ncb == 2) launch_skinny_ncb<2>(p, st);
     else if (ncb == 3) launch_skinny_ncb<3>(p, st);
-    else launch_skinny_ncb<4>(p, st);
+    else if (ncb == 4) launch_skinny_ncb<4>(p, st);
+    else if (ncb == 5) launch_skinny_ncb<5>(p, st);
+    else launch_skinny_ncb<6>(p, st);   // R <= 96 (nh_create rejects a larger max_batch)
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -366,9 +366,9 @@ extern "C" int nh_create(int device_ordinal, const nh_config *cfg, int max_batch
     const int d = cfg->d_model;
     if (d % 128 != 0 || d > 1280 || d / cfg->encoder_attention_heads != NH_DH ||
         d / cfg->decoder_attention_heads != NH_DH || cfg->max_source_positions != 1500 ||
-        (cfg->num_mel_bins != 80 && cfg->num_mel_bins != 128) || max_batch > 64) {
+        (cfg->num_mel_bins != 80 && cfg->num_mel_bins != 128) || max_batch > NH_MAX_BATCH) {
         g_create_error = "nh_create: unsupported config (need d_model % 128 == 0, d_model <= 1280, head dim 64, "
-                         "max_source_positions 1500, num_mel_bins 80|128, max_batch <= 64)";
+                         "max_source_positions 1500, num_mel_bins 80|128, max_batch <= 96)";
         return NH_ERR_INVALID;
     }
     int ndev = 0;
@@ -387,7 +387,7 @@ extern "C" int nh_create(int device_ordinal, const nh_config *cfg, int max_batch
 // A second (third ...) context on the SAME device over the SAME weights: own stream, workspaces, K/V caches, tokens and
 // decode state; the model tables are shared and reference counted (freed with the last context).
 extern "C" int nh_create_shared(nh_ctx *parent, int max_batch, nh_ctx **out) {
-    if (!parent || !out || max_batch < 1 || max_batch > 64) { g_create_error = "nh_create_shared: bad arguments (1 <= max_batch <= 64)"; return NH_ERR_INVALID; }
+    if (!parent || !out || max_batch < 1 || max_batch > NH_MAX_BATCH) { g_create_error = "nh_create_shared: bad arguments (1 <= max_batch <= 96)"; return NH_ERR_INVALID; }
     return build_context(parent->mdl, max_batch, out);
 }
 
@@ -596,8 +596,9 @@ extern "C" int nh_set_tokens(nh_ctx *ctx, const nh_tokens *tk, const int32_t *su
 }
 
 // ---- log-mel -------------------------------------------------------------------------------------------
-static int prepare_batch(nh_ctx *ctx, const int32_t *n_samples, int batch) {
-    if (batch < 1 || batch > ctx->B) return ctx->fail(NH_ERR_INVALID, "batch must be in [1, max_batch]");
+// row0 > 0: the clips join the rows already filled (several encoder batches of one joint decode, nh_logmel_device_rows)
+static int prepare_batch(nh_ctx *ctx, const int32_t *n_samples, int batch, int row0 = 0) {
+    if (batch < 1 || row0 < 0 || row0 + batch > ctx->B) return ctx->fail(NH_ERR_INVALID, "rows [row0, row0 + batch) must lie in [0, max_batch]");
     long fr = -1;
     for (int b = 0; b < batch; b++) {
         if (n_samples[b] < 1 || n_samples[b] > NH_N_SAMPLES)
@@ -606,6 +607,13 @@ static int prepare_batch(nh_ctx *ctx, const int32_t *n_samples, int batch) {
         if (f > NH_N_FRAMES) f = NH_N_FRAMES;  // narrow(2, 0, min(3000, frames)), model.rs:88
         if (fr < 0) fr = f;
         else if (fr != f) return ctx->fail(NH_ERR_INVALID, "clips of one batch must produce the same number of mel frames");
+    }
+    if (row0 > 0) {
+        if (row0 > ctx->cur_batch) return ctx->fail(NH_ERR_STATE, "row0 leaves a gap after the rows filled so far");
+        if ((int)fr != ctx->frames) return ctx->fail(NH_ERR_INVALID, "all rows of one joint decode must produce the same number of mel frames");
+        if (row0 + batch > ctx->cur_batch) ctx->cur_batch = row0 + batch;
+        ctx->have_enc = false;
+        return NH_OK;
     }
     ctx->cur_batch = batch; ctx->frames = (int)fr; ctx->S = (int)((fr + 2 - 3) / 2 + 1);
     ctx->have_mel = false; ctx->have_enc = false;
@@ -618,20 +626,30 @@ static int prepare_batch(nh_ctx *ctx, const int32_t *n_samples, int batch) {
     return NH_OK;
 }
 
-static int run_logmel(nh_ctx *ctx, const float *pcm_dev, const int32_t *n_samples, int64_t stride, int batch) {
+static int run_logmel(nh_ctx *ctx, const float *pcm_dev, const int32_t *n_samples, int64_t stride, int batch, int row0 = 0) {
     if (!ctx->mdl->have_filters) return ctx->fail(NH_ERR_STATE, "nh_logmel: mel filters not set");
-    int rc = prepare_batch(ctx, n_samples, batch);
+    int rc = prepare_batch(ctx, n_samples, batch, row0);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(ctx->nsamp, n_samples, sizeof(int32_t) * batch, hipMemcpyHostToDevice, ctx->st));
+    const int nm = ctx->c.num_mel_bins;
+    int32_t *nsamp = ctx->nsamp + row0;
+    unsigned *cmax = ctx->chunk_max + row0;
+    float *mel32 = ctx->mel32 + (size_t)row0 * nm * ctx->frames;
+    half_t *img = ctx->mel_img + (size_t)row0 * (ctx->frames + 2) * NH_MELP;
+    HIPCHK(hipMemcpyAsync(nsamp, n_samples, sizeof(int32_t) * batch, hipMemcpyHostToDevice, ctx->st));
     HIPCHK(hipEventRecord(ctx->ev[0], ctx->st));
-    HIPCHK(hipMemsetAsync(ctx->chunk_max, 0, sizeof(unsigned) * batch, ctx->st));
-    launch_logmel_grp(pcm_dev, ctx->nsamp, stride, ctx->mdl->mt, ctx->mdl->mel_grp, ctx->c.num_mel_bins, ctx->frames, ctx->mel32,
-                      ctx->chunk_max, batch, ctx->st);
-    launch_mel_finish_ex(ctx->mel32, ctx->chunk_max, ctx->mel_img, batch, ctx->c.num_mel_bins, ctx->frames, 1, ctx->st);
+    HIPCHK(hipMemsetAsync(cmax, 0, sizeof(unsigned) * batch, ctx->st));
+    launch_logmel_grp(pcm_dev, nsamp, stride, ctx->mdl->mt, ctx->mdl->mel_grp, nm, ctx->frames, mel32, cmax, batch, ctx->st);
+    launch_mel_finish_ex(mel32, cmax, img, batch, nm, ctx->frames, 1, ctx->st);
     HIPCHK(hipEventRecord(ctx->ev[1], ctx->st));
     HIPCHK(hipGetLastError());
     ctx->have_mel = true;
     return NH_OK;
+}
+
+extern "C" int nh_logmel_device_rows(nh_ctx *ctx, const float *pcm_dev, const int32_t *n_samples, int64_t stride, int batch, int row0) {
+    if (!ctx || !pcm_dev || !n_samples) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_logmel_device_rows: bad arguments") : NH_ERR_INVALID;
+    hipSetDevice(ctx->dev);
+    return run_logmel(ctx, pcm_dev, n_samples, stride, batch, row0);
 }
 
 extern "C" int nh_logmel_device(nh_ctx *ctx, const float *pcm_dev, const int32_t *n_samples, int64_t stride, int batch) {
@@ -640,16 +658,26 @@ extern "C" int nh_logmel_device(nh_ctx *ctx, const float *pcm_dev, const int32_t
     return run_logmel(ctx, pcm_dev, n_samples, stride, batch);
 }
 
-extern "C" int nh_logmel(nh_ctx *ctx, const float *pcm, const int32_t *n_samples, int64_t stride, int batch) {
-    if (!ctx || !pcm || !n_samples) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_logmel: bad arguments") : NH_ERR_INVALID;
+static int logmel_host_rows(nh_ctx *ctx, const float *pcm, const int32_t *n_samples, int64_t stride, int batch, int row0) {
     hipSetDevice(ctx->dev);
-    if (batch < 1 || batch > ctx->B) return ctx->fail(NH_ERR_INVALID, "batch must be in [1, max_batch]");
+    if (batch < 1 || row0 < 0 || row0 + batch > ctx->B) return ctx->fail(NH_ERR_INVALID, "rows [row0, row0 + batch) must lie in [0, max_batch]");
+    float *dst = ctx->pcm + (size_t)row0 * NH_N_SAMPLES;
     for (int b = 0; b < batch; b++) {
         if (n_samples[b] < 1 || n_samples[b] > NH_N_SAMPLES) return ctx->fail(NH_ERR_INVALID, "clip length must be in [1, 480000] samples");
-        HIPCHK(hipMemcpyAsync(ctx->pcm + (size_t)b * NH_N_SAMPLES, pcm + (size_t)b * stride, sizeof(float) * n_samples[b],
+        HIPCHK(hipMemcpyAsync(dst + (size_t)b * NH_N_SAMPLES, pcm + (size_t)b * stride, sizeof(float) * n_samples[b],
                               hipMemcpyHostToDevice, ctx->st));
     }
-    return run_logmel(ctx, ctx->pcm, n_samples, NH_N_SAMPLES, batch);
+    return run_logmel(ctx, dst, n_samples, NH_N_SAMPLES, batch, row0);
+}
+
+extern "C" int nh_logmel(nh_ctx *ctx, const float *pcm, const int32_t *n_samples, int64_t stride, int batch) {
+    if (!ctx || !pcm || !n_samples) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_logmel: bad arguments") : NH_ERR_INVALID;
+    return logmel_host_rows(ctx, pcm, n_samples, stride, batch, 0);
+}
+
+extern "C" int nh_logmel_rows(nh_ctx *ctx, const float *pcm, const int32_t *n_samples, int64_t stride, int batch, int row0) {
+    if (!ctx || !pcm || !n_samples) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_logmel_rows: bad arguments") : NH_ERR_INVALID;
+    return logmel_host_rows(ctx, pcm, n_samples, stride, batch, row0);
 }
 
 extern "C" int nh_sample_size(int dt) {
@@ -741,53 +769,71 @@ static void gemm_plain(nh_ctx *ctx, const half_t *A, long lda, const LinW &W, in
     gemm_prof_end(ctx, p);
 }
 
-extern "C" int nh_encode(nh_ctx *ctx) {
-    if (!ctx) return NH_ERR_INVALID;
+// Type::encoder_forward + the cross K/V of every decoder layer for the clips in rows [row0, row0 + B) of the context
+static int encode_rows(nh_ctx *ctx, int row0, int B) {
     if (!ctx->have_mel) return ctx->fail(NH_ERR_STATE, "nh_encode: call nh_logmel first");
     if (nh_missing_tensors(ctx) != 0) return ctx->fail(NH_ERR_STATE, "nh_encode: " + std::to_string(nh_missing_tensors(ctx)) + " tensors not loaded");
+    if (row0 < 0 || B < 1 || row0 + B > ctx->cur_batch) return ctx->fail(NH_ERR_INVALID, "nh_encode_rows: rows outside the clips given to nh_logmel");
     hipSetDevice(ctx->dev);
     ensure_views(ctx);
-    const int d = ctx->c.d_model, B = ctx->cur_batch, F = ctx->frames, S = ctx->S, H = ctx->c.encoder_attention_heads;
+    const int d = ctx->c.d_model, F = ctx->frames, S = ctx->S, H = ctx->c.encoder_attention_heads;
     const int M = B * S;
+    const size_t r0 = (size_t)row0;
+    // this group's slices of the per-clip workspaces
+    half_t *const mel_img = ctx->mel_img + r0 * (F + 2) * NH_MELP, *const h1 = ctx->h1 + r0 * (F + 2) * d;
+    float *const x = ctx->x + r0 * S * d, *const xa32 = ctx->xa32 + r0 * S * d;
+    half_t *const xn = ctx->xn + r0 * S * d, *const q = ctx->q + r0 * S * d, *const k = ctx->k + r0 * S * d, *const att = ctx->att + r0 * S * d;
+    half_t *const vt = ctx->vt + r0 * d * NH_SP, *const hid = ctx->hid + r0 * S * 4 * d, *const xa16 = ctx->xa16 + r0 * S * d;
     ctx->gemm_ev_used = 0; ctx->gemm_flops_acc = 0.0;
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->st));
     {   // conv1 + GELU: A rows overlap (lda = 128, K = 3 * 128) inside the zero-framed mel image
         GemmParams p{};
-        p.A = ctx->mel_img; p.lda = NH_MELP; p.a_rpb = F; p.a_bstride = (long)(F + 2) * NH_MELP;
+        p.A = mel_img; p.lda = NH_MELP; p.a_rpb = F; p.a_bstride = (long)(F + 2) * NH_MELP;
         p.W = ctx->conv1.w; p.bias = ctx->conv1.b; p.M = B * F; p.N = d; p.K = 3 * NH_MELP; p.epi = EPI_GELU_F16;
-        p.out[0] = ctx->h1; p.seg_n = d; p.ldo = d; p.o_rpb = F; p.o_bstride = F + 2; p.o_off = 1; p.vt_seg = -1;
+        p.out[0] = h1; p.seg_n = d; p.ldo = d; p.o_rpb = F; p.o_bstride = F + 2; p.o_off = 1; p.vt_seg = -1;
         p.S = S; p.H = H;
         gemm_prof_begin(ctx); launch_gemm(p, ctx->st); gemm_prof_end(ctx, p);
     }
     {   // conv2 (stride 2) + GELU + transpose + sinusoid positions -> f32 residual stream
         GemmParams p{};
-        p.A = ctx->h1; p.lda = 2L * d; p.a_rpb = S; p.a_bstride = (long)(F + 2) * d;
+        p.A = h1; p.lda = 2L * d; p.a_rpb = S; p.a_bstride = (long)(F + 2) * d;
         p.W = ctx->conv2.w; p.bias = ctx->conv2.b; p.M = M; p.N = d; p.K = 3 * d; p.epi = EPI_CONV2_F32;
-        p.out[0] = ctx->x; p.seg_n = d; p.ldo = d; p.o_rpb = M; p.o_bstride = 0; p.o_off = 0; p.vt_seg = -1;
+        p.out[0] = x; p.seg_n = d; p.ldo = d; p.o_rpb = M; p.o_bstride = 0; p.o_off = 0; p.vt_seg = -1;
         p.S = S; p.H = H; p.pos = ctx->enc_pos;
         gemm_prof_begin(ctx); launch_gemm(p, ctx->st); gemm_prof_end(ctx, p);
     }
     for (auto &L : ctx->enc) {
-        launch_layernorm(ctx->x, L.ln1.w, L.ln1.b, ctx->xn, nullptr, M, d, ctx->st);
+        launch_layernorm(x, L.ln1.w, L.ln1.b, xn, nullptr, M, d, ctx->st);
         // q leaves the GEMM as (x W_q + b_q) * dh^-1/2 * log2(e): candle's q * dh^-1/4 and k * dh^-1/4 and the
         // exp -> exp2 change of base, applied once in f32 before the one rounding to fp16 (k_attn_enc.hip)
-        gemm_plain(ctx, ctx->xn, d, L.qkv, M, 3 * d, d, EPI_F16, ctx->q, ctx->k, ctx->vt, d, d, 2, 0, NH_ENC_Q_SCALE);
-        launch_enc_attention(ctx->q, ctx->k, d, ctx->vt, ctx->att, d, B, S, H, ctx->st);
-        gemm_plain(ctx, ctx->att, d, L.o, M, d, d, EPI_RESID_F32, ctx->x, nullptr, nullptr, d, d, -1);
-        launch_layernorm(ctx->x, L.ln2.w, L.ln2.b, ctx->xn, nullptr, M, d, ctx->st);
-        gemm_plain(ctx, ctx->xn, d, L.fc1, M, 4 * d, d, EPI_GELU_F16, ctx->hid, nullptr, nullptr, 4 * d, 4 * d, -1);
-        gemm_plain(ctx, ctx->hid, 4 * d, L.fc2, M, d, 4 * d, EPI_RESID_F32, ctx->x, nullptr, nullptr, d, d, -1);
+        gemm_plain(ctx, xn, d, L.qkv, M, 3 * d, d, EPI_F16, q, k, vt, d, d, 2, 0, NH_ENC_Q_SCALE);
+        launch_enc_attention(q, k, d, vt, att, d, B, S, H, ctx->st);
+        gemm_plain(ctx, att, d, L.o, M, d, d, EPI_RESID_F32, x, nullptr, nullptr, d, d, -1);
+        launch_layernorm(x, L.ln2.w, L.ln2.b, xn, nullptr, M, d, ctx->st);
+        gemm_plain(ctx, xn, d, L.fc1, M, 4 * d, d, EPI_GELU_F16, hid, nullptr, nullptr, 4 * d, 4 * d, -1);
+        gemm_plain(ctx, hid, 4 * d, L.fc2, M, d, 4 * d, EPI_RESID_F32, x, nullptr, nullptr, d, d, -1);
     }
-    launch_layernorm(ctx->x, ctx->ln_post.w, ctx->ln_post.b, ctx->xa16, ctx->xa32, M, d, ctx->st);
+    launch_layernorm(x, ctx->ln_post.w, ctx->ln_post.b, xa16, xa32, M, d, ctx->st);
     HIPCHK(hipEventRecord(ctx->ev[3], ctx->st));
-    // cross-attention K/V of every decoder layer (the flush = true work of MultiHeadAttention::forward)
+    // cross-attention K/V of every decoder layer (the flush = true work of MultiHeadAttention::forward), head-major
+    // [b][h][S][64]: clip row0 starts at row0 * S * d
     for (auto &L : ctx->dec)
-        gemm_plain(ctx, ctx->xa16, d, L.ckv, M, 2 * d, d, EPI_F16, L.ck, L.cv, nullptr, d, d, -1, 1);  // [b][h][S][64]
+        gemm_plain(ctx, xa16, d, L.ckv, M, 2 * d, d, EPI_F16, L.ck + r0 * S * d, L.cv + r0 * S * d, nullptr, d, d, -1, 1);
     HIPCHK(hipEventRecord(ctx->ev[4], ctx->st));
     HIPCHK(hipEventRecord(ctx->enc_done, ctx->st));
     HIPCHK(hipGetLastError());
     ctx->have_enc = true;
     return NH_OK;
+}
+
+extern "C" int nh_encode(nh_ctx *ctx) {
+    if (!ctx) return NH_ERR_INVALID;
+    return encode_rows(ctx, 0, ctx->cur_batch);
+}
+
+extern "C" int nh_encode_rows(nh_ctx *ctx, int row0, int batch) {
+    if (!ctx) return NH_ERR_INVALID;
+    return encode_rows(ctx, row0, batch);
 }
 
 extern "C" int nh_encoder_output(nh_ctx *ctx, int b, float *out) {

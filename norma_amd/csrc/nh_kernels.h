@@ -65,7 +65,7 @@ __device__ __forceinline__ int nh_div(int m, int d, unsigned magic) {
 void launch_gemm(const GemmParams &p, hipStream_t st);
 void launch_gemm_128(const GemmParams &p, hipStream_t st);  // always the 128 x 128 kernel
 
-// ---- skinny GEMM for the decoder: y[R][N] = x[R][K] . W[N][K]^T, R <= 64 rows -------------------
+// ---- skinny GEMM for the decoder: y[R][N] = x[R][K] . W[N][K]^T, R <= 96 rows -------------------
 enum SkinnyEpi {
     SK_F16 = 0,         // fp16 out (row stride ldo, per-row base offsets)
     SK_GELU_F16 = 1,

@@ -93,6 +93,9 @@ def load_library() -> C.CDLL:
     L.nh_missing_tensors.argtypes = [vp]
     L.nh_logmel.argtypes = [vp, fp, ip, C.c_int64, C.c_int]
     L.nh_logmel_device.argtypes = [vp, vp, ip, C.c_int64, C.c_int]
+    L.nh_logmel_rows.argtypes = [vp, fp, ip, C.c_int64, C.c_int, C.c_int]
+    L.nh_logmel_device_rows.argtypes = [vp, vp, ip, C.c_int64, C.c_int, C.c_int]
+    L.nh_encode_rows.argtypes = [vp, C.c_int, C.c_int]
     L.nh_logmel_samples.argtypes = [vp, vp, C.c_int, ip, C.c_int64, C.c_int]
     L.nh_sample_size.argtypes = [C.c_int]
     L.nh_encode.argtypes = [vp]
@@ -230,6 +233,23 @@ class HipWhisper:
         ns = np.asarray(n_samples, dtype=np.int32)
         self._chk(self.L.nh_logmel_device(self._h, C.c_void_p(pcm_dev_ptr), _ip(ns), stride, len(ns)))
         self.batch = len(ns)
+
+    def logmel_device_rows(self, pcm_dev_ptr: int, n_samples: Sequence[int], stride: int, row0: int):
+        """Clips for rows [row0, row0 + len(n_samples)) of the context (several encoder batches, one joint decode)."""
+        ns = np.asarray(n_samples, dtype=np.int32)
+        self._chk(self.L.nh_logmel_device_rows(self._h, C.c_void_p(pcm_dev_ptr), _ip(ns), stride, len(ns), row0))
+        self.batch = row0 + len(ns) if row0 > 0 else len(ns)
+
+    def logmel_array_rows(self, pcm: np.ndarray, row0: int):
+        """pcm: contiguous f32 [batch][stride] in HOST memory -> rows [row0, row0 + batch)."""
+        assert pcm.dtype == np.float32 and pcm.ndim == 2 and pcm.flags.c_contiguous
+        B, stride = pcm.shape
+        ns = np.full(B, stride, dtype=np.int32)
+        self._chk(self.L.nh_logmel_rows(self._h, _fp(pcm), _ip(ns), stride, B, row0))
+        self.batch = row0 + B if row0 > 0 else B
+
+    def encode_rows(self, row0: int, batch: int):
+        self._chk(self.L.nh_encode_rows(self._h, row0, batch))
 
     def get_mel(self, b: int, frames: int = N_FRAMES) -> np.ndarray:
         out = np.zeros((self.cfg.num_mel_bins, frames), dtype=np.float32)

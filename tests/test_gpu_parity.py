@@ -434,3 +434,46 @@ def test_distil_large_v3_full_depth_one_clip_matches_the_oracle():
     assert abs(got["avg_logprob"] - ref["avg_logprob"]) <= 5e-3
     assert abs(got["no_speech_prob"] - ref["no_speech_prob"]) <= 0.02 * ref["no_speech_prob"] + 1e-9
     hm.close(); om.close()
+
+
+def test_encoder_batches_decoded_together_give_what_they_give_alone():
+    """nh_logmel_device_rows / nh_encode_rows + one nh_decode_greedy over all rows (r03: the decoder weights and the tied
+    embedding are streamed once per token for several encoder batches).  Rows filled 32 + 32 (distil-large-v3: the 64-row
+    logits run through two K-phases of skinny_ldsp_kernel) and 8 + 8 + 5 on a small model (ragged last group, 96-row
+    dispatch with 6 row blocks at 16 + 40 + 40): every clip's tokens, log-probs and encoder output must equal, bit for bit,
+    what the same clip gives in a batch of its own."""
+    hip = _hip()
+    for name, groups, script_seed in (("test-d256-mel128", (8, 8, 5), 17), ("test-d256-mel128", (16, 40, 40), 18),
+                                      ("distil-large-v3", (32, 32), 3)):
+        cfg = config.preset(name)
+        tk = common.tokens_for(name)
+        script = common.transcript_script(tk, n_segments=3, words_per_segment=5, seed=script_seed)
+        over = common.scripted_overrides(cfg, tk, script)
+        total = sum(groups)
+        hm = common.build_hip(cfg, tk, overrides=over, max_batch=total)
+        h1 = hip.HipWhisper(cfg, device=0, max_batch=max(groups), share_with=hm)
+        h1.set_tokens(tk, tk.en, tk.transcribe)
+        clips = np.stack([synth.synth_pcm(k) for k in range(total)])
+        row0, alone = 0, []
+        for g in groups:
+            part = np.ascontiguousarray(clips[row0:row0 + g])
+            hm.logmel_array_rows(part, row0)
+            hm.encode_rows(row0, g)
+            h1.logmel_array(part); h1.encode()
+            alone.extend(h1.decode_greedy())
+            if row0 == 0:
+                enc_alone = h1.encoder_output(g - 1)
+                enc_row = g - 1
+            row0 += g
+        joint = hm.decode_greedy()
+        assert len(joint) == total == len(alone)
+        for a, b in zip(joint, alone):
+            assert a["tokens"] == b["tokens"] == [tk.sot, tk.en, tk.transcribe] + script
+            assert a["avg_logprob"] == b["avg_logprob"] and a["no_speech_prob"] == b["no_speech_prob"]
+        assert np.array_equal(hm.encoder_output(enc_row), enc_alone)
+        assert len({r["avg_logprob"] for r in joint}) > 1
+        # a new set of rows starts over at row 0; a gap is refused
+        hm.logmel_array_rows(np.ascontiguousarray(clips[:groups[0]]), 0)
+        with pytest.raises(hip.HipError):
+            hm.logmel_array_rows(np.ascontiguousarray(clips[:2]), groups[0] + 1)
+        hm.close(); h1.close()
