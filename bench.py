@@ -439,6 +439,8 @@ def worker(args):
         except Exception:
             traffic = None
         gemm_tflops = tm_timed["gemm_flops"] / (tm_timed["gemm_ms"] * 1e-3) / 1e12 if tm_timed and tm_timed["gemm_ms"] > 0 else 0.0
+        if tm and tm is not tm_timed and tm["gemm_ms"] > 0:   # the same launches with nothing else on the GPU (no queueing behind other contexts)
+            extra["gemm_tflops_one_batch_at_a_time"] = tm["gemm_flops"] / (tm["gemm_ms"] * 1e-3) / 1e12
         n_tok = int(np.mean([len(r["tokens"]) for r in res])) if res else 0
         # per-phase roofline fractions of the last timed step of rank 0 (algorithmic work / phase time / nominal peak)
         phases = []
@@ -486,6 +488,9 @@ def worker(args):
                          "unit": "TFLOP/s", "frac": gemm_tflops / MFMA_PEAK_TFLOPS, "traffic": traffic,
                          "traffic_note": "bytes per launch from profiles/pmc_hbm_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, "
                                          "Infinity-Cache hits included; last profiled value, not live)",
+                         "achieved_note": "algorithmic FLOPs / sum of event-bracketed launch durations of one step INSIDE the timed region; with "
+                                          "several batches in flight a launch's bracket includes its wait behind other contexts' kernels "
+                                          "(rocprofv3 kernel durations: profiles/r03_default_kernel_stats.csv; alone: extra.gemm_tflops_one_batch_at_a_time)",
                          "launches": tm_timed["gemm_launches"] if tm_timed else 0,
                          "avg_launch_ms": tm_timed["gemm_ms"] / max(tm_timed["gemm_launches"], 1) if tm_timed else None,
                          "flops_per_step": tm_timed["gemm_flops"] if tm_timed else None,
