@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 K=$1; shift
 rm -rf /tmp/p1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --pipelines 1 --no-single-extra "$@" > /tmp/p1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p1 -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --pipelines 1 --decode-groups 1 --no-single-extra "$@" > /tmp/p1.log 2>&1
 f=$(find /tmp/p1 -name "*kernel_stats.csv" | head -1)
 python3 - "$f" "$K" <<'PY'
 import csv,sys

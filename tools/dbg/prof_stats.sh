@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/prof_$1
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --pipelines 1 > /tmp/prof_$1.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$1 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --pipelines 1 --decode-groups 1 > /tmp/prof_$1.log 2>&1
 f=$(find /tmp/prof_$1 -name "*kernel_stats.csv" | head -1)
 cp "$f" $R/gpurun_out/$1_kernel_stats.csv
 python3 - "$f" <<'PY'
