@@ -59,8 +59,8 @@ MFMA_PEAK_TFLOPS = 2500.0  # dense fp16 (no sparsity)
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=12)   # a multiple of pipelines x decode-groups, so that every decode is a joint one
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="b32")
     ap.add_argument("--model", default=None, help="override the workload's model (parity-test sizes on small boxes)")
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU (workload b32)")
