@@ -345,12 +345,12 @@ def worker(args):
             return out
         last = [None] * P
 
+        # the n batches are dealt to the pipelines in units of G (one joint decode each; a last, smaller unit if G does not divide n)
+        units = [G] * (n // G) + ([n % G] if n % G else [])
+
         def worker_thread(i):
-            mine = len(range(i, n, P))            # steps (32-clip batches) this pipeline owns
-            while mine > 0:
-                g = min(G, mine)
+            for g in units[i::P]:
                 last[i] = step(max_new, hms[i], pipelined=True) if G == 1 else group_step(max_new, hms[i], g)
-                mine -= g
         ths = [threading.Thread(target=worker_thread, args=(i,)) for i in range(P)]
         for t in ths:
             t.start()
