@@ -160,6 +160,29 @@ int nh_encode_rows(nh_ctx *ctx, int row0, int batch);
 /* Greedy decode of all `batch` sequences.  out_tokens: host i32 [batch][max_target_positions],
  * results: [batch].  max_new_tokens <= 0: reference behaviour (cap at max_target_positions - 1). */
 int nh_decode_greedy(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *results, int max_new_tokens);
+/* Decode pool (r03): sequences that join and leave a running decode.  The reference's loop ends per sequence at eot
+ * (model.rs:317); decoded as one lockstep batch the short sequences wait for the longest.  Here rows [0, rows) of the context
+ * decode, every row at its own position, and the rows above them are encoder staging:
+ *   nh_pool_begin(ctx, 64, 0, 0);
+ *   nh_logmel_rows(ctx, pcm, n, stride, 32, 64);  nh_encode_rows(ctx, 64, 32);      32 clips -> staging rows 64 .. 95
+ *   nh_pool_admit(ctx, 64 + i, free_row, -1);                                      clip i joins the decode at position 0
+ *   nh_pool_step(ctx, 16, done);                                                   16 tokens for every busy row
+ *   nh_pool_collect(ctx, rows_done, k, tokens, results);                           finished rows out, their slots are free again
+ * A row's prompt ([sot, lang?, task], model.rs:285-289), no-speech probe and exit (:293-315), rules, length cap (:367) and
+ * result (:373-381) are those of nh_decode_greedy, and so are its bits: the same step kernels run, only the position is read
+ * per row.  All clips of a pool must produce the same number of mel frames.  nh_logmel* with row0 = 0 ends the pool.
+ * per_clip_language != 0: the prompt carries a language token given per clip at nh_pool_admit (LanguageState::Detect);
+ * otherwise nh_tokens.lang decides, as in nh_decode_greedy, and `lang` must be -1. */
+int nh_pool_begin(nh_ctx *ctx, int rows, int max_new_tokens, int per_clip_language);
+/* The clip encoded at staging row src_row (>= rows) starts decoding in the free row dst_row (< rows): its cross K/V move
+ * (device-to-device, 4 * S * d_model bytes per decoder layer), its decode state starts over.  Asynchronous. */
+int nh_pool_admit(nh_ctx *ctx, int src_row, int dst_row, int32_t lang);
+/* n_steps decode steps (one token per busy, unfinished row each), then done_out[rows]: 0 running, 1 finished, 2 finished by
+ * the no-speech exit, 3 empty.  Returns when the steps have run. */
+int nh_pool_step(nh_ctx *ctx, int n_steps, int32_t *done_out);
+/* Results of the n finished rows `rows[]`: out_tokens host i32 [n][max_target_positions], results [n]; the rows are free
+ * for nh_pool_admit afterwards. */
+int nh_pool_collect(nh_ctx *ctx, const int32_t *rows, int n, int32_t *out_tokens, nh_decode_result *results);
 /* Model::decode at t > 0 (model.rs:340-348): every token is SAMPLED from softmax(q / t), q = the rule-masked
  * probabilities.  The reference draws with rand::WeightedIndex from an entropy-seeded StdRng (model.rs:30), so only its
  * distribution can be reproduced; this build fixes a seeded SAMPLING CONTRACT (the C oracle implements the same, bit for bit):

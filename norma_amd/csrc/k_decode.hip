@@ -61,7 +61,7 @@ __device__ __forceinline__ void skinny_store(const SkinnyParams &p, f32x4 v, int
         half_t *dst;
         if (sg == 0) dst = reinterpret_cast<half_t *>(p.out[0]) + (long)r * p.d + nl;
         else {
-            const int t0 = p.pos_ptr ? *p.pos_ptr : p.t0;
+            const int t0 = p.pos_ptr ? p.pos_ptr[b] : p.t0;  // per-sequence position (decode pool / hipGraph replay)
             // self-attention K/V cache, head-major [b][h][ctx][64]: the keys of one (clip, head) are contiguous for dec_attn_kernel
             dst = reinterpret_cast<half_t *>(sg == 1 ? p.out[1] : p.out[2]) +
                   (((long)b * (p.d >> 6) + (nl >> 6)) * p.ctx + t0 + i) * NH_DH + (nl & 63);
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict_
     // sequence at eot (model.rs:317); in a batch the others go on, and 0.49 GB of the 0.72 GB a step streams is per-sequence
     // cross K/V.  Its attention row is left as it was; every later product is row-wise, nothing of it reaches another row.
     if (done && done[blockIdx.y]) return;
-    if (pos_ptr) Tk = *pos_ptr + 1;
+    if (pos_ptr) Tk = pos_ptr[blockIdx.y] + 1;  // causal self-attention at this sequence's own position
     __shared__ float part[4][8][10];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int slot = lane >> 3, pp = lane & 7;
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict_
 void launch_dec_attention(const half_t *q, const half_t *kc, const half_t *vc, half_t *out, int B, int Tn,
                           int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st, int kv_head_major,
                           const int32_t *done) {
-    (void)Tn;  // one new position per sequence; its visible keys are exactly Tk (or *pos_ptr + 1)
+    (void)Tn;  // one new position per sequence; its visible keys are exactly Tk (or pos_ptr[b] + 1)
     hipLaunchKernelGGL(dec_attn_kernel, dim3(H, B), dim3(256), 0, st, q, kc, vc, out, d, ctx, Tk, pos_ptr, kv_head_major, done);
 }
 
@@ -1077,8 +1077,6 @@ __global__ __launch_bounds__(256) void logit_step_kernel(const float *__restrict
                                                          DecodeState s, RuleTokens tk, int ctx, int cap, int max_new,
                                                          int prompt_len, int mode, float *partials, unsigned *tickets,
                                                          int32_t *pos_ptr) {
-    // nothing in this launch reads the position; every earlier kernel of the step has completed
-    if (pos_ptr && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *pos_ptr += 1;
     __shared__ float sh_f[4][6];
     __shared__ int sh_i[4][2];
     __shared__ int sh_last;
@@ -1098,11 +1096,24 @@ __global__ __launch_bounds__(256) void logit_step_kernel(const float *__restrict
     }
     const int32_t *toks = s.tokens + (long)b * ctx;
     const int done = s.done[b];
+    const int my_pos = pos_ptr ? pos_ptr[b] : 0;  // this sequence's position; advanced below by whoever finishes its step
     const int n = s.n_tokens[b];
     const int have_last = s.have_last[b], last_ts = s.last_ts[b];
     const double sum_lp_in = s.sum_logprob[b];  // prefetched for the bookkeeping at the end
     const int l1 = toks[n >= 1 ? n - 1 : 0], l2 = toks[n >= 2 ? n - 2 : 0];  // unconditional: one round trip for both
     if (done) return;
+    // mode 2 (decode pool): sequences join a running decode, so each is in its own phase -- position 0 of its prompt is the
+    // no-speech probe, the other prompt positions only feed the caches (their next token is given), then it generates
+    if (mode == 2) {
+        mode = my_pos == 0 ? 0 : (my_pos < prompt_len - 1 ? 3 : 1);
+        if (mode == 3) {  // the position moves only when all LSPLIT workgroups of the sequence have read it: same ticket as below
+            if (tid == 0 && __hip_atomic_fetch_add(tickets + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == LSPLIT - 1) {
+                __hip_atomic_store(tickets + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pos_ptr[b] = my_pos + 1;
+            }
+            return;
+        }
+    }
     const int NT = tk.no_timestamps;
     // candidate sets: A = allowed non-timestamp tokens (or the first-token window), B = allowed timestamps
     int kind;  // 0 FIRST, 1 SUP_TS, 2 NON_TS, 3 TEXT (NON_TS vs PAST decided at the end), 4 no-speech probe
@@ -1203,8 +1214,10 @@ __global__ __launch_bounds__(256) void logit_step_kernel(const float *__restrict
         float p = expf(lg[tk.no_speech] - m) / se;
         s.no_speech[b] = (double)p;
         if ((double)p > 0.6) s.done[b] = 2;
+        if (pos_ptr) pos_ptr[b] = my_pos + 1;
         return;
     }
+    if (pos_ptr) pos_ptr[b] = my_pos + 1;  // every workgroup of this sequence read it before taking its ticket
     int next = -1; float lnext = 0.f;
     if (kind == 0 || kind == 1) { next = ai; lnext = av; }
     else if (kind == 2) { next = bi; lnext = bv; }
@@ -1236,6 +1249,18 @@ void launch_logit_step(const float *logits, int V, DecodeState s, RuleTokens tk,
     int ldl = (V + 63) & ~63;
     hipLaunchKernelGGL(logit_step_kernel, dim3(LSPLIT, B), dim3(256), 0, st, logits, V, ldl, s, tk, ctx, cap, max_new,
                        prompt_len, mode, partials, tickets, pos_ptr);
+}
+
+// decode pool: sequence `row` starts over with the prompt [t0, t1, (t2)] (model.rs:285-289) at position 0
+__global__ void pool_admit_kernel(DecodeState s, int32_t *pos, unsigned *tickets, int row, int ctx, int t0, int t1, int t2, int P) {
+    int32_t *t = s.tokens + (long)row * ctx;
+    t[0] = t0; t[1] = t1; if (P == 3) t[2] = t2;
+    s.n_tokens[row] = P; s.done[row] = 0; s.have_last[row] = 0; s.last_ts[row] = 0;
+    s.sum_logprob[row] = 0.0; s.no_speech[row] = 0.0;
+    pos[row] = 0; tickets[row] = 0u;
+}
+void launch_pool_admit(DecodeState s, int32_t *pos, unsigned *tickets, int row, int ctx, int t0, int t1, int t2, int P, hipStream_t st) {
+    hipLaunchKernelGGL(pool_admit_kernel, dim3(1), dim3(1), 0, st, s, pos, tickets, row, ctx, t0, t1, t2, P);
 }
 
 // Model::detect_language (model.rs:194-210) on the position-0 logits of a [sot] prompt: softmax over the language

@@ -82,9 +82,9 @@ __global__ __launch_bounds__(256) void embed_kernel(const int32_t *__restrict__ 
                                                     const half_t *__restrict__ E, const half_t *__restrict__ P,
                                                     float *__restrict__ x, int Tn, int t0,
                                                     const int32_t *__restrict__ pos_ptr, int d) {
-    if (pos_ptr) t0 = *pos_ptr;
     const int r = blockIdx.x;  // row = b * Tn + i
     const int b = r / Tn, i = r - b * Tn;
+    if (pos_ptr) t0 = pos_ptr[b];  // per-sequence position
     const int tok = tokens[(long)b * tok_stride + t0 + i];
     const half_t *e = E + (long)tok * d, *p = P + (long)(t0 + i) * d;
     for (int c = threadIdx.x * 4; c < d; c += 256 * 4) {

@@ -100,10 +100,14 @@ struct nh_ctx {
     uint8_t *suppress = nullptr;
     float *lpart = nullptr;
     unsigned *ltick = nullptr;
-    int32_t *d_pos = nullptr;  // device-side decode position (hipGraph replays read it)
+    int32_t *d_pos = nullptr;  // [max_batch] device-side decode position of every sequence (hipGraph replays read and advance it)
+    // decode pool (nh_pool_*): rows [0, pool_rows) decode, each at its own position; rows above are encoder staging
+    int pool_rows = 0, pool_max_new = 0, pool_prompt = 0;
+    bool pool_per_clip_language = false;
+    std::vector<char> pool_busy;
     hipGraphExec_t step_graph = nullptr;   // one decode step
     hipGraphExec_t multi_graph = nullptr;  // NH_GRAPH_STEPS consecutive steps (one launch gap instead of NH_GRAPH_STEPS)
-    int graph_key[5] = {-1, -1, -1, -1, -1};
+    int graph_key[6] = {-1, -1, -1, -1, -1, -1};
     int token_gen = 0;  // bumped by nh_set_tokens; part of the graph key
     bool opt_graphs = true, opt_fuse_ln = true;  // nh_set_option
     int dec_layer_limit = 0;    // parity view (NH_OPT_DECODER_LAYER_LIMIT): run only the first n decoder blocks; 0 = all
@@ -349,11 +353,11 @@ static int build_context(std::shared_ptr<nh_model> mdl, int max_batch, nh_ctx **
     DA(dxn, half_t, (long)B * d); DA(dq, half_t, (long)B * d); DA(datt, half_t, (long)B * d); DA(dhid, half_t, (long)B * 4 * d);
     DA(ds.tokens, int32_t, (long)B * ctxlen); DA(ds.n_tokens, int32_t, B); DA(ds.done, int32_t, B);
     DA(ds.have_last, int32_t, B); DA(ds.last_ts, int32_t, B); DA(ds.sum_logprob, double, B); DA(ds.no_speech, double, B);
-    DA(ds.n_active, int32_t, 1); DA(suppress, uint8_t, V); DA(lpart, float, (long)B * 64); DA(ltick, unsigned, B); DA(d_pos, int32_t, 4); DA(d_lang_tokens, int32_t, 256); DA(d_lang_out, int32_t, B); DA(d_lang_probs, float, (long)B * 256);
+    DA(ds.n_active, int32_t, 1); DA(suppress, uint8_t, V); DA(lpart, float, (long)B * 64); DA(ltick, unsigned, B); DA(d_pos, int32_t, B); DA(d_lang_tokens, int32_t, 256); DA(d_lang_out, int32_t, B); DA(d_lang_probs, float, (long)B * 256);
 #undef DA
     if (!ok) { ctx->err = "hipMalloc failed while sizing the context (out of device memory?)"; return bail(NH_ERR_NOMEM); }
     ctx->ds.suppress = ctx->suppress;
-    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_done), sizeof(int32_t) * 128, 0) != hipSuccess) {
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_done), sizeof(int32_t) * 256, 0) != hipSuccess) {
         ctx->err = "hipHostMalloc failed"; return bail(NH_ERR_NOMEM);
     }
     refresh_views(ctx);
@@ -608,6 +612,19 @@ static int prepare_batch(nh_ctx *ctx, const int32_t *n_samples, int batch, int r
         if (fr < 0) fr = f;
         else if (fr != f) return ctx->fail(NH_ERR_INVALID, "clips of one batch must produce the same number of mel frames");
     }
+    if (ctx->pool_rows > 0 && row0 >= ctx->pool_rows) {  // decode pool: encoder staging rows above the decoding ones
+        if (ctx->frames < 0) {
+            ctx->frames = (int)fr; ctx->S = (int)((fr + 2 - 3) / 2 + 1);
+            if (ctx->frames != ctx->last_frames) {
+                HIPCHK(hipMemsetAsync(ctx->mel_img, 0, sizeof(half_t) * (size_t)ctx->B * (NH_N_FRAMES + 2) * NH_MELP, ctx->st));
+                HIPCHK(hipMemsetAsync(ctx->h1, 0, sizeof(half_t) * (size_t)ctx->B * (NH_N_FRAMES + 2) * ctx->c.d_model, ctx->st));
+                ctx->last_frames = ctx->frames;
+            }
+        } else if ((int)fr != ctx->frames) return ctx->fail(NH_ERR_INVALID, "all clips of one decode pool must produce the same number of mel frames");
+        if (row0 + batch > ctx->cur_batch) ctx->cur_batch = row0 + batch;
+        ctx->have_enc = false;
+        return NH_OK;
+    }
     if (row0 > 0) {
         if (row0 > ctx->cur_batch) return ctx->fail(NH_ERR_STATE, "row0 leaves a gap after the rows filled so far");
         if ((int)fr != ctx->frames) return ctx->fail(NH_ERR_INVALID, "all rows of one joint decode must produce the same number of mel frames");
@@ -617,6 +634,7 @@ static int prepare_batch(nh_ctx *ctx, const int32_t *n_samples, int batch, int r
     }
     ctx->cur_batch = batch; ctx->frames = (int)fr; ctx->S = (int)((fr + 2 - 3) / 2 + 1);
     ctx->have_mel = false; ctx->have_enc = false;
+    ctx->pool_rows = 0;  // a fresh batch ends a decode pool
     ctx->seq_lang.clear();
     if (ctx->frames != ctx->last_frames) {  // the zero rows framing each clip move with the frame count
         HIPCHK(hipMemsetAsync(ctx->mel_img, 0, sizeof(half_t) * (size_t)ctx->B * (NH_N_FRAMES + 2) * NH_MELP, ctx->st));
@@ -882,7 +900,7 @@ static void ln_skinny(nh_ctx *ctx, const LnW &ln, const LinW &W, int R, int N, i
 // skip_done: finished sequences skip their attention (only inside decode_impl, where ds.done is live).
 static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr, bool final_ln = true, bool skip_done = false) {
     const int32_t *done = skip_done ? ctx->ds.done : nullptr;
-    const int d = ctx->c.d_model, B = ctx->cur_batch, H = ctx->c.decoder_attention_heads, C = ctx->c.max_target_positions;
+    const int d = ctx->c.d_model, B = ctx->pool_rows > 0 ? ctx->pool_rows : ctx->cur_batch, H = ctx->c.decoder_attention_heads, C = ctx->c.max_target_positions;
     launch_embed(ctx->ds.tokens, C, ctx->tok_emb, ctx->dec_pos, ctx->dx, B, 1, pos, pos_ptr, d, ctx->sd);
     int nl = 0;
     for (auto &L : ctx->dec) {
@@ -917,6 +935,23 @@ static void logits_from_dxn(nh_ctx *ctx, int R) {
            ctx->VP, 0, 0);
 }
 
+// what Model::decode returns for one sequence from the state its loop left behind (model.rs:308-315, 373-381)
+static void finish_sequence(nh_ctx *ctx, int32_t *t, int n, int done, double slp, double nsp, int32_t *out_tokens, nh_decode_result &r) {
+    const int C = ctx->c.max_target_positions;
+    r.no_speech_prob = nsp;
+    r.no_speech_exit = (done == 2);
+    if (done == 2) { r.avg_logprob = 0.0; }  // model.rs:308-315
+    else {
+        r.avg_logprob = slp / (double)n;  // model.rs:373 (prompt and eot count)
+        while (n >= 2 && t[n - 2] > ctx->tk.no_timestamps) { t[n - 2] = t[n - 1]; n--; }  // :375-381
+    }
+    r.n_tokens = n;
+    memcpy(out_tokens, t, sizeof(int32_t) * C);
+    for (int i = n; i < C; i++) out_tokens[i] = 0;
+}
+
+static int capture_step_graphs(nh_ctx *ctx, int B, int max_new_tokens, int P, int mode);
+
 // Model::decode (model.rs:279-389) for the whole batch.  inv_t == 0: t = 0, greedy (hipGraph replay); inv_t > 0: every
 // token is sampled at temperature 1 / inv_t under the seeded contract (eager launches: the fallback path is rare).
 static int decode_impl(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *results, int max_new_tokens, float inv_t,
@@ -924,6 +959,7 @@ static int decode_impl(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *resul
     if (!ctx || !out_tokens || !results) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_decode: bad arguments") : NH_ERR_INVALID;
     if (!ctx->have_enc) return ctx->fail(NH_ERR_STATE, "nh_decode: call nh_encode first");
     if (!ctx->have_tokens) return ctx->fail(NH_ERR_STATE, "nh_decode: call nh_set_tokens first");
+    if (ctx->pool_rows > 0) return ctx->fail(NH_ERR_STATE, "nh_decode: the context runs a decode pool (nh_pool_begin); a batch submitted with row0 = 0 ends it");
     hipSetDevice(ctx->dev);
     if (int rc = ensure_decoder_repack(ctx)) return rc;
     const int B = ctx->cur_batch, C = ctx->c.max_target_positions, cap = C - 1, V = ctx->c.vocab_size;
@@ -964,37 +1000,15 @@ static int decode_impl(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *resul
     // pos + 2 >= cap, so pos never exceeds cap - 2.  The ~20-launch step is captured (once, and 8 steps back to back) into hipGraphs that
     // reads the position from device memory (the eager loop is host-launch-bound at ~5 us per tiny kernel).
     const bool no_graph = !ctx->opt_graphs || inv_t > 0.f;
-    const int key[5] = {B, ctx->S, max_new_tokens, P, ctx->token_gen};
+    const int key[6] = {B, ctx->S, max_new_tokens, P, ctx->token_gen, 0};
     if (!no_graph && memcmp(key, ctx->graph_key, sizeof(key)) != 0) {
         drop_graphs(ctx);
-        for (int which = 0; which < 2; which++) {
-            hipGraph_t g = nullptr;
-            hipError_t ge = hipStreamBeginCapture(ctx->sd, hipStreamCaptureModeThreadLocal);
-            if (ge != hipSuccess) return ctx->fail(NH_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(ge));
-            for (int i = 0; i < (which ? NH_GRAPH_STEPS : 1); i++) {  // every step reads and advances the device-side position
-                decoder_step(ctx, 0, ctx->d_pos, false, true);
-                logits_from_dx(ctx, B);
-                launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, 1, ctx->lpart, ctx->ltick, ctx->d_pos, ctx->sd);
-            }
-            // the stream must leave capture mode whatever happened in between; a failed capture leaves no graph behind
-            ge = hipStreamEndCapture(ctx->sd, &g);
-            if (ge == hipSuccess && !g) ge = hipErrorStreamCaptureInvalidated;
-            if (ge == hipSuccess) {
-                ge = hipGraphInstantiate(which ? &ctx->multi_graph : &ctx->step_graph, g, nullptr, nullptr, 0);
-                if (ge != hipSuccess) (which ? ctx->multi_graph : ctx->step_graph) = nullptr;
-            }
-            if (g) hipGraphDestroy(g);
-            if (ge != hipSuccess) {
-                (void)hipGetLastError();
-                drop_graphs(ctx);
-                return ctx->fail(NH_ERR_HIP, std::string("decode-step graph capture: ") + hipGetErrorString(ge));
-            }
-        }
+        if (int rc = capture_step_graphs(ctx, B, max_new_tokens, P, 1)) return rc;
         memcpy(ctx->graph_key, key, sizeof(key));
     }
     const int32_t first_pos = P - 1;
-    ctx->h_done[100] = first_pos;
-    HIPCHK(hipMemcpyAsync(ctx->d_pos, &ctx->h_done[100], sizeof(int32_t), hipMemcpyHostToDevice, ctx->sd));
+    for (int b = 0; b < B; b++) ctx->h_done[128 + b] = first_pos;  // every sequence of a batch starts generating at the same position
+    HIPCHK(hipMemcpyAsync(ctx->d_pos, ctx->h_done + 128, sizeof(int32_t) * B, hipMemcpyHostToDevice, ctx->sd));
     // positions first_pos .. cap - 2; the host looks at the done flags every 16 steps (and after the last one)
     for (int pos = first_pos; pos <= cap - 2;) {
         int n = 1;
@@ -1030,21 +1044,8 @@ static int decode_impl(nh_ctx *ctx, int32_t *out_tokens, nh_decode_result *resul
     HIPCHK(hipMemcpyAsync(nsp.data(), ctx->ds.no_speech, B * 8, hipMemcpyDeviceToHost, ctx->sd));
     HIPCHK(hipStreamSynchronize(ctx->sd));
     HIPCHK(hipGetLastError());
-    for (int b = 0; b < B; b++) {
-        int32_t *t = toks.data() + (size_t)b * C;
-        int n = nt[b];
-        nh_decode_result &r = results[b];
-        r.no_speech_prob = nsp[b];
-        r.no_speech_exit = (done[b] == 2);
-        if (done[b] == 2) { r.avg_logprob = 0.0; }  // model.rs:308-315
-        else {
-            r.avg_logprob = slp[b] / (double)n;  // model.rs:373 (prompt and eot count)
-            while (n >= 2 && t[n - 2] > ctx->tk.no_timestamps) { t[n - 2] = t[n - 1]; n--; }  // :375-381
-        }
-        r.n_tokens = n;
-        memcpy(out_tokens + (size_t)b * C, t, sizeof(int32_t) * C);
-        for (int i = n; i < C; i++) out_tokens[(size_t)b * C + i] = 0;
-    }
+    for (int b = 0; b < B; b++)
+        finish_sequence(ctx, toks.data() + (size_t)b * C, nt[b], done[b], slp[b], nsp[b], out_tokens + (size_t)b * C, results[b]);
     ctx->tm.decode_steps = steps;
     return NH_OK;
 }
@@ -1057,6 +1058,144 @@ extern "C" int nh_decode_sampled(nh_ctx *ctx, int32_t *out_tokens, nh_decode_res
                                  float temperature, uint64_t seed, uint32_t clip0, uint32_t attempt) {
     if (ctx && !(temperature > 0.f)) return ctx->fail(NH_ERR_INVALID, "nh_decode_sampled: temperature must be > 0 (use nh_decode_greedy for t = 0)");
     return decode_impl(ctx, out_tokens, results, max_new_tokens, 1.0f / temperature, seed, clip0, attempt);
+}
+
+// ---- decode pool -------------------------------------------------------------------------------------------
+// The reference's loop ends per sequence at eot (model.rs:317), so the sequences of a batch do not finish together.
+// Rows [0, rows) of the context decode, every row at its own position; a finished row is handed back (nh_pool_collect)
+// and refilled (nh_pool_admit) from the encoder staging rows [rows, max_batch) while the others go on.  Every row's
+// arithmetic is what it is in nh_decode_greedy -- the step kernels are the same, only the position is per row.
+extern "C" int nh_pool_begin(nh_ctx *ctx, int rows, int max_new_tokens, int per_clip_language) {
+    if (!ctx) return NH_ERR_INVALID;
+    if (rows < 1 || rows >= ctx->B) return ctx->fail(NH_ERR_INVALID, "nh_pool_begin: rows must lie in [1, max_batch - 1] (the rows above are encoder staging)");
+    if (!ctx->have_tokens) return ctx->fail(NH_ERR_STATE, "nh_pool_begin: call nh_set_tokens first");
+    hipSetDevice(ctx->dev);
+    if (int rc = ensure_decoder_repack(ctx)) return rc;
+    ctx->pool_rows = rows; ctx->pool_max_new = max_new_tokens;
+    ctx->pool_prompt = (per_clip_language || ctx->tk.lang >= 0) ? 3 : 2;
+    ctx->pool_per_clip_language = per_clip_language != 0;
+    ctx->pool_busy.assign(rows, 0);
+    ctx->cur_batch = rows; ctx->frames = -1; ctx->S = 0; ctx->have_mel = false; ctx->have_enc = false;
+    ctx->seq_lang.clear();
+    for (int b = 0; b < rows; b++) ctx->h_done[128 + b] = 3;  // 3: empty row (skipped like a finished one)
+    HIPCHK(hipMemcpyAsync(ctx->ds.done, ctx->h_done + 128, sizeof(int32_t) * rows, hipMemcpyHostToDevice, ctx->sd));
+    HIPCHK(hipMemsetAsync(ctx->d_pos, 0, sizeof(int32_t) * rows, ctx->sd));
+    HIPCHK(hipMemsetAsync(ctx->ltick, 0, sizeof(unsigned) * rows, ctx->sd));
+    HIPCHK(hipStreamSynchronize(ctx->sd));
+    return NH_OK;
+}
+
+extern "C" int nh_pool_admit(nh_ctx *ctx, int src_row, int dst_row, int32_t lang) {
+    if (!ctx) return NH_ERR_INVALID;
+    if (ctx->pool_rows < 1) return ctx->fail(NH_ERR_STATE, "nh_pool_admit: no decode pool (nh_pool_begin)");
+    if (!ctx->have_enc || src_row < ctx->pool_rows || src_row >= ctx->cur_batch) return ctx->fail(NH_ERR_STATE, "nh_pool_admit: src_row is not an encoded staging row (nh_encode_rows)");
+    if (dst_row < 0 || dst_row >= ctx->pool_rows || ctx->pool_busy[dst_row]) return ctx->fail(NH_ERR_INVALID, "nh_pool_admit: dst_row is not a free row of the pool");
+    const int P = ctx->pool_prompt;
+    if (!ctx->pool_per_clip_language && lang >= 0) return ctx->fail(NH_ERR_INVALID, "nh_pool_admit: the pool was begun without per-clip languages");
+    int32_t lg = lang >= 0 ? lang : ctx->tk.lang;
+    if (P == 3 && (lg < 0 || lg >= ctx->c.vocab_size)) return ctx->fail(NH_ERR_INVALID, "nh_pool_admit: language token outside the vocabulary");
+    hipSetDevice(ctx->dev);
+    const size_t per = (size_t)ctx->S * ctx->c.d_model;  // cross K / V of one clip and layer, head-major [h][S][64]
+    for (auto &L : ctx->dec) {
+        HIPCHK(hipMemcpyAsync(L.ck + per * dst_row, L.ck + per * src_row, per * sizeof(half_t), hipMemcpyDeviceToDevice, ctx->sd));
+        HIPCHK(hipMemcpyAsync(L.cv + per * dst_row, L.cv + per * src_row, per * sizeof(half_t), hipMemcpyDeviceToDevice, ctx->sd));
+    }
+    // model.rs:285-289: prompt = [sot, lang?, task]
+    launch_pool_admit(ctx->ds, ctx->d_pos, ctx->ltick, dst_row, ctx->c.max_target_positions, ctx->tk.sot, P == 3 ? lg : ctx->tk.task,
+                      ctx->tk.task, P, ctx->sd);
+    HIPCHK(hipGetLastError());
+    ctx->pool_busy[dst_row] = 1;
+    return NH_OK;
+}
+
+static int capture_step_graphs(nh_ctx *ctx, int B, int max_new_tokens, int P, int mode) {
+    const int C = ctx->c.max_target_positions, cap = C - 1, V = ctx->c.vocab_size;
+    for (int which = 0; which < 2; which++) {
+        hipGraph_t g = nullptr;
+        hipError_t ge = hipStreamBeginCapture(ctx->sd, hipStreamCaptureModeThreadLocal);
+        if (ge != hipSuccess) return ctx->fail(NH_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(ge));
+        for (int i = 0; i < (which ? NH_GRAPH_STEPS : 1); i++) {  // every step reads and advances the device-side positions
+            decoder_step(ctx, 0, ctx->d_pos, false, true);
+            logits_from_dx(ctx, B);
+            launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, max_new_tokens, P, mode, ctx->lpart, ctx->ltick, ctx->d_pos, ctx->sd);
+        }
+        // the stream must leave capture mode whatever happened in between; a failed capture leaves no graph behind
+        ge = hipStreamEndCapture(ctx->sd, &g);
+        if (ge == hipSuccess && !g) ge = hipErrorStreamCaptureInvalidated;
+        if (ge == hipSuccess) {
+            ge = hipGraphInstantiate(which ? &ctx->multi_graph : &ctx->step_graph, g, nullptr, nullptr, 0);
+            if (ge != hipSuccess) (which ? ctx->multi_graph : ctx->step_graph) = nullptr;
+        }
+        if (g) hipGraphDestroy(g);
+        if (ge != hipSuccess) {
+            (void)hipGetLastError();
+            drop_graphs(ctx);
+            return ctx->fail(NH_ERR_HIP, std::string("decode-step graph capture: ") + hipGetErrorString(ge));
+        }
+    }
+    return NH_OK;
+}
+
+extern "C" int nh_pool_step(nh_ctx *ctx, int n_steps, int32_t *done_out) {
+    if (!ctx || !done_out) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_pool_step: bad arguments") : NH_ERR_INVALID;
+    if (ctx->pool_rows < 1) return ctx->fail(NH_ERR_STATE, "nh_pool_step: no decode pool (nh_pool_begin)");
+    if (n_steps < 0) return ctx->fail(NH_ERR_INVALID, "nh_pool_step: n_steps < 0");
+    const int B = ctx->pool_rows, C = ctx->c.max_target_positions, cap = C - 1, V = ctx->c.vocab_size, P = ctx->pool_prompt;
+    hipSetDevice(ctx->dev);
+    bool any = false;
+    for (int b = 0; b < B; b++) any = any || ctx->pool_busy[b];
+    if (any && n_steps > 0) {
+        if (ctx->S < 1) return ctx->fail(NH_ERR_STATE, "nh_pool_step: rows are busy but nothing was ever encoded");
+        if (ctx->opt_graphs) {
+            const int key[6] = {B, ctx->S, ctx->pool_max_new, P, ctx->token_gen, 1};
+            if (memcmp(key, ctx->graph_key, sizeof(key)) != 0) {
+                drop_graphs(ctx);
+                if (int rc = capture_step_graphs(ctx, B, ctx->pool_max_new, P, 2)) return rc;
+                memcpy(ctx->graph_key, key, sizeof(key));
+            }
+        }
+        for (int left = n_steps; left > 0;) {
+            if (!ctx->opt_graphs) {
+                decoder_step(ctx, 0, ctx->d_pos, false, true);
+                logits_from_dx(ctx, B);
+                launch_logit_step(ctx->logits, V, ctx->ds, ctx->tk, B, C, cap, ctx->pool_max_new, P, 2, ctx->lpart, ctx->ltick, ctx->d_pos, ctx->sd);
+                left--;
+            } else if (left >= NH_GRAPH_STEPS) { HIPCHK(hipGraphLaunch(ctx->multi_graph, ctx->sd)); left -= NH_GRAPH_STEPS; }
+            else { HIPCHK(hipGraphLaunch(ctx->step_graph, ctx->sd)); left--; }
+        }
+        ctx->tm.decode_steps += n_steps;
+    }
+    HIPCHK(hipMemcpyAsync(ctx->h_done, ctx->ds.done, B * 4, hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipStreamSynchronize(ctx->sd));
+    HIPCHK(hipGetLastError());
+    for (int b = 0; b < B; b++) done_out[b] = ctx->pool_busy[b] ? ctx->h_done[b] : 3;
+    return NH_OK;
+}
+
+extern "C" int nh_pool_collect(nh_ctx *ctx, const int32_t *rows, int n, int32_t *out_tokens, nh_decode_result *results) {
+    if (!ctx || !rows || !out_tokens || !results || n < 1) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_pool_collect: bad arguments") : NH_ERR_INVALID;
+    if (ctx->pool_rows < 1) return ctx->fail(NH_ERR_STATE, "nh_pool_collect: no decode pool (nh_pool_begin)");
+    const int B = ctx->pool_rows, C = ctx->c.max_target_positions;
+    for (int i = 0; i < n; i++)
+        if (rows[i] < 0 || rows[i] >= B || !ctx->pool_busy[rows[i]]) return ctx->fail(NH_ERR_INVALID, "nh_pool_collect: not a busy row of the pool");
+    hipSetDevice(ctx->dev);
+    std::vector<int32_t> toks((size_t)n * C), nt(B), done(B);
+    std::vector<double> slp(B), nsp(B);
+    for (int i = 0; i < n; i++)
+        HIPCHK(hipMemcpyAsync(toks.data() + (size_t)i * C, ctx->ds.tokens + (size_t)rows[i] * C, sizeof(int32_t) * C, hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipMemcpyAsync(nt.data(), ctx->ds.n_tokens, B * 4, hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipMemcpyAsync(done.data(), ctx->ds.done, B * 4, hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipMemcpyAsync(slp.data(), ctx->ds.sum_logprob, B * 8, hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipMemcpyAsync(nsp.data(), ctx->ds.no_speech, B * 8, hipMemcpyDeviceToHost, ctx->sd));
+    HIPCHK(hipStreamSynchronize(ctx->sd));
+    for (int i = 0; i < n; i++)
+        if (done[rows[i]] != 1 && done[rows[i]] != 2) return ctx->fail(NH_ERR_STATE, "nh_pool_collect: that row has not finished (see nh_pool_step's done flags)");
+    for (int i = 0; i < n; i++) {
+        const int b = rows[i];
+        finish_sequence(ctx, toks.data() + (size_t)i * C, nt[b], done[b], slp[b], nsp[b], out_tokens + (size_t)i * C, results[i]);
+        ctx->pool_busy[b] = 0;
+    }
+    return NH_OK;
 }
 
 extern "C" int nh_sample_rules(nh_ctx *ctx, const float *probs, const int32_t *tokens, int n_tokens, int last_timestamp,

@@ -82,7 +82,7 @@ struct SkinnyParams {
     void *out[3]; long ldo;
     // SK_QKV: row r = b*Tn + i  (Tn new positions per sequence); k, v go to the head-major caches [b][h][ctx][64] at t0 + i
     int d, t0, Tn, ctx;
-    const int32_t *pos_ptr;  // when set, t0 is read from device memory (hipGraph replay of the decode step)
+    const int32_t *pos_ptr;  // when set: i32 [B], sequence b writes its K/V at pos_ptr[b] (hipGraph replay of the decode step)
     // LayerNorm fused into the activation load (skinny_ln_supported): x is ignored, the activations are
     // LN(ln_x[r][0..K)) * ln_w + ln_b (eps 1e-5, two-pass f32 statistics), rounded to fp16 like layernorm_kernel does
     const float *ln_x, *ln_w, *ln_b;
@@ -197,7 +197,7 @@ void launch_enc_attention(const half_t *q, const half_t *k, long ld, const half_
 
 // ---- decoder attention (one query row per (b, h, i)) -------------------------------------------------
 // q: fp16 [B*Tn][d]; kc,vc: fp16 [B][ctx][d]; keys visible to new row i: t0 + i + 1 (causal) or Tk (cross)
-// pos_ptr != nullptr: causal self-attention over *pos_ptr + 1 keys (device-side position)
+// pos_ptr != nullptr: i32 [B]; sequence b attends causally over pos_ptr[b] + 1 keys (device-side positions)
 // kv_head_major: K/V are [b][h][ctx][64] (the cross K/V written with GemmParams::head_major) instead of [b][ctx][d]
 // done: optional i32 [B]; sequences with done[b] != 0 are skipped (their output row is left untouched)
 void launch_dec_attention(const half_t *q, const half_t *kc, const half_t *vc, half_t *out, int B, int Tn,
@@ -217,12 +217,16 @@ struct DecodeState {        // all device pointers
     const uint8_t *suppress;  // [V] 1 = suppressed (suppress_tokens U {no_timestamps})
 };
 struct RuleTokens { int sot, eot, lang, task, no_speech, no_timestamps, zero_sec, one_sec; };
-// mode 0: no-speech probe at prompt position 0; mode 1: generate a token from logits [B][V]
+// mode 0: no-speech probe at prompt position 0; mode 1: generate a token from logits [B][V]; mode 2 (decode pool): every
+// sequence is in the phase its own position pos_ptr[b] says -- 0: no-speech probe, < prompt_len - 1: nothing (the next prompt
+// token is given), otherwise generate
 // partials: f32 [B][8][8] scratch, tickets: u32 [B] zero-initialised (the kernel re-zeroes them)
-// pos_ptr != nullptr: the kernel advances the device-side position after the step
+// pos_ptr != nullptr: i32 [B], the position of every sequence; the kernel advances those it stepped
 void launch_logit_step(const float *logits, int V, DecodeState s, RuleTokens tk, int B, int ctx, int cap,
                        int max_new, int prompt_len, int mode, float *partials, unsigned *tickets, int32_t *pos_ptr,
                        hipStream_t st);
+// decode pool: sequence `row` restarts at position 0 with the prompt [t0, t1] (P = 2) or [t0, t1, t2] (P = 3)
+void launch_pool_admit(DecodeState s, int32_t *pos, unsigned *tickets, int row, int ctx, int t0, int t1, int t2, int P, hipStream_t st);
 // t > 0: one SAMPLED token per sequence (model.rs:340-348) under the seeded contract of include/norma_hip.h;
 // sequence b draws with clip id clip0 + b, step = its current token count
 void launch_sample_step(const float *logits, int V, DecodeState s, RuleTokens tk, int B, int ctx, int cap, int max_new,

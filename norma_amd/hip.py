@@ -96,6 +96,10 @@ def load_library() -> C.CDLL:
     L.nh_logmel_rows.argtypes = [vp, fp, ip, C.c_int64, C.c_int, C.c_int]
     L.nh_logmel_device_rows.argtypes = [vp, vp, ip, C.c_int64, C.c_int, C.c_int]
     L.nh_encode_rows.argtypes = [vp, C.c_int, C.c_int]
+    L.nh_pool_begin.argtypes = [vp, C.c_int, C.c_int, C.c_int]
+    L.nh_pool_admit.argtypes = [vp, C.c_int, C.c_int, C.c_int32]
+    L.nh_pool_step.argtypes = [vp, C.c_int, ip]
+    L.nh_pool_collect.argtypes = [vp, ip, C.c_int, ip, C.POINTER(NhDecodeResult)]
     L.nh_logmel_samples.argtypes = [vp, vp, C.c_int, ip, C.c_int64, C.c_int]
     L.nh_sample_size.argtypes = [C.c_int]
     L.nh_encode.argtypes = [vp]
@@ -250,6 +254,29 @@ class HipWhisper:
 
     def encode_rows(self, row0: int, batch: int):
         self._chk(self.L.nh_encode_rows(self._h, row0, batch))
+
+    # ---- decode pool (include/norma_hip.h: nh_pool_*): rows [0, rows) decode at their own positions, the rows above stage
+    # encoder output; norma_amd/pool.py holds the refill policy
+    def pool_begin(self, rows: int, max_new_tokens: int = 0, per_clip_language: bool = False):
+        self._chk(self.L.nh_pool_begin(self._h, rows, max_new_tokens, int(per_clip_language)))
+        self.pool_rows = rows
+
+    def pool_admit(self, src_row: int, dst_row: int, lang: int = -1):
+        self._chk(self.L.nh_pool_admit(self._h, src_row, dst_row, lang))
+
+    def pool_step(self, n_steps: int) -> np.ndarray:
+        """n_steps tokens for every busy row; returns the rows' flags (0 running, 1 finished, 2 no-speech exit, 3 empty)."""
+        done = np.zeros(self.pool_rows, dtype=np.int32)
+        self._chk(self.L.nh_pool_step(self._h, n_steps, _ip(done)))
+        return done
+
+    def pool_collect(self, rows: Sequence[int]) -> List[dict]:
+        rows = np.asarray(rows, dtype=np.int32)
+        toks = np.zeros((len(rows), self.cfg.max_target_positions), dtype=np.int32)
+        res = (NhDecodeResult * len(rows))()
+        self._chk(self.L.nh_pool_collect(self._h, _ip(rows), len(rows), _ip(toks), res))
+        return [dict(tokens=toks[i, :res[i].n_tokens].tolist(), avg_logprob=res[i].avg_logprob,
+                     no_speech_prob=res[i].no_speech_prob, no_speech_exit=bool(res[i].no_speech_exit)) for i in range(len(rows))]
 
     def get_mel(self, b: int, frames: int = N_FRAMES) -> np.ndarray:
         out = np.zeros((self.cfg.num_mel_bins, frames), dtype=np.float32)

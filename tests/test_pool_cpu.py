@@ -1,0 +1,81 @@
+"""CPU: the decode pool's refill policy (norma_amd/pool.py) against a counting stand-in for the engine -- every clip is
+admitted once into a free row, collected once after it finished, results come back in clip order, the encoder is fed
+`staging` clips at a time.  (The reference decodes one stream at a time, src/lib.rs:462-464, and ends each sequence at eot,
+model.rs:317: no counterpart; the GPU side is tests/test_gpu_pool.py.)"""
+import numpy as np
+import pytest
+
+from norma_amd import pool
+
+
+class FakeEngine:
+    def __init__(self, lengths, prompt=3):
+        self.lengths, self.prompt = lengths, prompt
+        self.log = []
+
+    def pool_begin(self, rows, max_new, per_clip_language):
+        self.rows = rows
+        self.left = [None] * rows          # steps still to run per row (None: empty)
+        self.clip = [None] * rows
+        self.staged = {}
+        self.lang = [None] * rows
+        self.max_concurrent = 0
+
+    def encode(self, first, n, row0):
+        assert row0 == self.rows
+        self.staged = {row0 + i: first + i for i in range(n)}
+        self.log.append(("encode", first, n))
+
+    def pool_admit(self, src, dst, lang):
+        assert self.left[dst] is None and src in self.staged
+        c = self.staged.pop(src)
+        self.clip[dst], self.left[dst], self.lang[dst] = c, self.lengths[c] + self.prompt - 1, lang
+        self.log.append(("admit", c, dst))
+
+    def pool_step(self, n):
+        self.max_concurrent = max(self.max_concurrent, sum(l is not None for l in self.left))
+        flags = np.zeros(self.rows, dtype=np.int32)
+        for r in range(self.rows):
+            if self.left[r] is None:
+                flags[r] = 3
+            else:
+                self.left[r] = max(0, self.left[r] - n)
+                flags[r] = 1 if self.left[r] == 0 else 0
+        return flags
+
+    def pool_collect(self, rows):
+        out = []
+        for r in rows:
+            assert self.left[r] == 0
+            out.append(dict(clip=self.clip[r], lang=self.lang[r]))
+            self.left[r] = None
+        return out
+
+
+@pytest.mark.parametrize("rows,staging,check", [(4, 3, 2), (8, 8, 16), (2, 5, 1), (64, 32, 16)])
+def test_every_clip_is_admitted_once_collected_once_and_returned_in_clip_order(rows, staging, check):
+    rng = np.random.default_rng(rows * 100 + staging)
+    N = 57
+    lengths = [int(x) for x in rng.choice([3, 10, 40, 41, 120], size=N)]
+    e = FakeEngine(lengths)
+    dp = pool.DecodePool(e, rows=rows, staging=staging, check_every=check)
+    seen = []
+    res = dp.run(N, e.encode, langs=list(range(1000, 1000 + N)), on_result=lambda c, r: seen.append(c))
+    assert [r["clip"] for r in res] == list(range(N)) and [r["lang"] for r in res] == list(range(1000, 1000 + N))
+    assert sorted(seen) == list(range(N))
+    assert [x[1] for x in e.log if x[0] == "admit"] == list(range(N))          # admitted in clip order
+    enc = [x for x in e.log if x[0] == "encode"]
+    assert [x[1] for x in enc] == list(range(0, N, staging)) and sum(x[2] for x in enc) == N
+    assert dp.encodes == len(enc) and e.max_concurrent <= rows
+    assert dp.row_steps >= sum(lengths) and dp.steps % check == 0
+    if N > rows + staging:
+        assert e.max_concurrent == rows                                        # the pool does fill up
+
+
+def test_pool_keeps_rows_busy_where_lockstep_batches_wait_for_the_longest():
+    lengths = [300 if k % 16 == 0 else 20 for k in range(256)]
+    e = FakeEngine(lengths, prompt=1)
+    dp = pool.DecodePool(e, rows=32, staging=32, check_every=4)
+    dp.run(len(lengths), e.encode)
+    lockstep = sum(32 * max(lengths[g:g + 32]) for g in range(0, len(lengths), 32))
+    assert dp.row_steps < 0.5 * lockstep
