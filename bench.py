@@ -87,6 +87,9 @@ def parse_args(argv=None):
                          "line reports that share's time and the job throughput N such ranks would give")
     ap.add_argument("--balance", action="store_true",
                     help="workload varlen: `value` is the length-bucketed / partition_balanced pass (default: arrival order)")
+    ap.add_argument("--pool-contexts", type=int, default=2, help="workload varlen: decode pools in flight per GPU")
+    ap.add_argument("--pool", action="store_true",
+                    help="workload varlen: `value` is the decode-pool pass (norma_amd/pool.py; default: arrival-order lockstep batches)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: the ranks rendezvous (gloo), partition the job, exchange placeholder results "
                          "through the real gather and print the JSON line with value null (CPU rehearsal of the N > 1 path)")
@@ -628,6 +631,79 @@ def worker_varlen(args, cfg, tk, world, rank, local_rank, dev, backend, gather_d
     balanced = shard.partition_balanced(steps, world)           # measured lengths -> ranks (LPT), then buckets inside a rank
     res_b, _, t_b = timed(balanced, lambda mine: shard.length_buckets(mine, steps, BMAX))
     identical = [a["tokens"] for a in res_a] == [b["tokens"] for b in res_b]
+    # (c) the decode pool (nh_pool_*, norma_amd/pool.py): the same chunks as ONE stream of steps x job clips in arrival order
+    # -- nothing is known about their lengths -- through POOL_ROWS decode rows that are refilled as sequences finish
+    from norma_amd import pool
+    POOL_ROWS = 64
+    import threading
+    NPOOL = max(1, args.pool_contexts)      # pools in flight on this GPU: one's encoder submission overlaps the others' decode steps
+    hmps = [hip.HipWhisper(cfg, device=local_rank, max_batch=POOL_ROWS + BMAX, share_with=hm) for _ in range(NPOOL)]
+    stages = [torch.empty((BMAX, synth.N_SAMPLES), dtype=torch.float32, device=dev) for _ in range(NPOOL)]
+    for h in hmps:
+        h.set_tokens(tk, tk.en, tk.transcribe)
+    stream = args.steps * job
+    s0, cnt = shard.partition(stream, world)[rank]
+    enc_lock = threading.Lock()
+
+    def pool_pass(first, count):
+        parts = shard.partition(count, NPOOL)
+        out, dps, errs = [None] * NPOOL, [None] * NPOOL, []
+
+        def one(i):
+            try:
+                torch.cuda.set_device(dev)
+                hmp, stg, (p0, pc) = hmps[i], stages[i], parts[i]
+                dp = pool.DecodePool(hmp, rows=POOL_ROWS, staging=BMAX, check_every=16)
+
+                def encode(f, n, row0, must):
+                    # one encoder submission at a time on the GPU; the decode steps of the other pools run beside it, and a pool
+                    # that still has rows decoding does not wait for the encoder (must = False): it steps on and asks again
+                    if not enc_lock.acquire(blocking=must):
+                        return False
+                    try:
+                        idx = torch.tensor([(first + p0 + f + k) % job for k in range(n)], dtype=torch.long, device=dev)
+                        torch.index_select(pcm_all, 0, idx, out=stg[:n])
+                        torch.cuda.synchronize()
+                        hmp.logmel_device_rows(stg.data_ptr(), [synth.N_SAMPLES] * n, synth.N_SAMPLES, row0)
+                        hmp.encode_rows(row0, n)
+                        hmp.synchronize()
+                    finally:
+                        enc_lock.release()
+                    return True
+                out[i] = dp.run(pc, encode) if pc else []
+                dps[i] = dp
+            except BaseException as e:   # noqa: BLE001 -- re-raised on the main thread
+                errs.append(e)
+        ths = [threading.Thread(target=one, args=(i,)) for i in range(NPOOL)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        if errs:
+            raise errs[0]
+        tot = pool.DecodePool(None, rows=POOL_ROWS, staging=BMAX)
+        for d in dps:
+            tot.row_steps += d.row_steps; tot.steps += d.steps; tot.encodes += d.encodes
+        return [r for part in out for r in part], tot
+    pool_pass(0, min(job, cnt)); barrier()
+    t0 = time.perf_counter()
+    res_p, dp = pool_pass(s0, cnt)
+    if world > 1:
+        shard.gather_results(res_p, stream, C, device=gather_dev)
+    barrier()
+    t_p = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([t_p], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t_p = float(t.item())
+    pool_same = all(r["tokens"] == res_a[(s0 + i) % job]["tokens"] and r["avg_logprob"] == res_a[(s0 + i) % job]["avg_logprob"]
+                    for i, r in enumerate(res_p))
+    pool_bad = [(s0 + i, r["tokens"] == res_a[(s0 + i) % job]["tokens"], r["avg_logprob"] - res_a[(s0 + i) % job]["avg_logprob"])
+                for i, r in enumerate(res_p) if r["tokens"] != res_a[(s0 + i) % job]["tokens"] or r["avg_logprob"] != res_a[(s0 + i) % job]["avg_logprob"]]
+    pool_stats = torch.tensor([dp.row_steps, dp.steps, dp.encodes, int(pool_same)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(pool_stats, op=dist.ReduceOp.SUM)
+    pool_stats = [float(v) for v in pool_stats.tolist()]
     tm = hm.timings()
     if rank == 0:
         def summary(assign, batches_of, t):
@@ -642,25 +718,34 @@ def worker_varlen(args, cfg, tk, world, rank, local_rank, dev, backend, gather_d
                     "wasted_row_step_frac": 1.0 - need_rs / max(run_rs, 1), "decode_steps_per_rank": loads}
         sa = summary(contiguous, arrival, t_a)
         sb = summary(balanced, lambda mine: shard.length_buckets(mine, steps, BMAX), t_b)
-        t_val = t_b if args.balance else t_a
+        need_stream = args.steps * sum(steps)
+        sp = {"xrt": stream * 30.0 / t_p, "ms_per_job": t_p * 1e3 / args.steps, "stream_chunks": stream, "pools_per_gpu": NPOOL, "decode_rows": POOL_ROWS,
+              "staging_rows": BMAX, "check_every": 16, "row_steps_run": pool_stats[0], "row_steps_needed": need_stream,
+              "wasted_row_step_frac": 1.0 - need_stream / max(pool_stats[0], 1.0), "decode_steps_launched": pool_stats[1],
+              "encoder_submissions": pool_stats[2], "same_tokens_and_logprobs_as_lockstep": pool_stats[3] == world,
+              "mismatches_rank0": pool_bad[:12], "mismatch_indices_rank0": [b[0] for b in pool_bad], "n_mismatches_rank0": len(pool_bad)}
+        t_val = t_p / args.steps if args.pool else (t_b if args.balance else t_a)
         gemm_tflops = tm["gemm_flops"] / (tm["gemm_ms"] * 1e-3) / 1e12 if tm["gemm_ms"] > 0 else 0.0
         out = {"metric": "audio-sec/wall-sec (xRT) distil-large-v3 fp16, variable decode lengths", "value": job * 30.0 / t_val,
                "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps, "warmup": 1, "ms_per_step": t_val * 1e3,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": f"{job} x 30 s chunks whose transcripts end at different steps (audio-decided eot votes at text "
                                       f"steps {VARLEN_EOT_STEPS}), batches of <= {BMAX}, " +
-                                      ("length-bucketed batches dealt with partition_balanced" if args.balance else "arrival-order batches"),
+                                      ("one stream through a 64-row decode pool (sequences join and leave a running decode)" if args.pool else
+                                       "length-bucketed batches dealt with partition_balanced" if args.balance else "arrival-order batches"),
                           "name": "varlen", "chunks": job, "batch_per_gpu": BMAX, "parallelism": f"chunk-dp{world}"},
                "roofline": {"bound": "mfma", "kernel": "gemm256_f16_kernel", "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS,
                             "unit": "TFLOP/s", "frac": gemm_tflops / MFMA_PEAK_TFLOPS, "traffic": None},
                "cpu_baseline": None,
                "extra": {"decode_steps": {"min": min(steps), "median": int(np.median(steps)), "mean": float(np.mean(steps)), "max": max(steps),
                                           "histogram": {str(v): steps.count(v) for v in sorted(set(steps))}},
-                         "arrival_order": sa, "length_bucketed": sb, "same_tokens_both_ways": identical}}
+                         "arrival_order": sa, "length_bucketed": sb, "decode_pool": sp, "same_tokens_both_ways": identical}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    for h in hmps:
+        h.close()
     hm.close()
     return 0
 

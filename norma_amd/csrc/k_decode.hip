@@ -16,6 +16,7 @@
 #include <atomic>
 
 #include "nh_kernels.h"
+#include <cstdlib>
 
 __device__ __forceinline__ float gelu_tanh_d(float v) { return gelu_tanh_fast(v); }
 
@@ -581,6 +582,21 @@ void launch_repack_tiles(const half_t *W, half_t *out, int N, int K, hipStream_t
     hipLaunchKernelGGL(repack_tiles_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, out, N, K);
 }
 
+// The two logits kernels above keep their activations in LDS and feed every MFMA from a `ds_read_b128` -- 512 threads, 288-358
+// of a SIMD's 512 registers, 40-120 KB of LDS: other kernels' workgroups fit beside them on a CU.  r03 found that they must not:
+// the log-mel kernel of ANOTHER context (37 KB of LDS, 4 waves) gave wrong spectra in 1-250 frames of a clip whenever one of these
+// workgroups ran beside it (tools/dbg/stress_mel.py: 150-190 wrong clip-mels in 3200 next to 64-row decodes, 6 in 9600 next to
+// 32-row ones, none next to 16-row ones or with nothing running; `tools/ldsprobe` shows LDS allocations and barriers of
+// co-resident workgroups do stay apart).  Stripping the kernel showed what it takes: the LDS read feeding the MFMA -- without the
+// MFMAs (LDS reads into VALU adds), or with the MFMA's B operand taken from registers instead, the neighbour's results are right;
+// stores, weight loads and the staging writes do not matter.  No software contract covers that, so these kernels do not share
+// their CU's LDS: they ask for all of it, which keeps every LDS-using workgroup off the CU while they run (30 us per token).
+#define NH_LDS_EXCLUSIVE (160 * 1024)
+static size_t lds_exclusive_bytes(size_t needed) {
+    static const bool share = getenv("NH_DBG_SHARE_LDS") != nullptr;   // tools/dbg/stress_mel.py's A/B switch: only what the kernel uses
+    return share ? needed : (size_t)NH_LDS_EXCLUSIVE;
+}
+
 static bool ln_steps_ok(int K) {
     const int s = K / 128;
     return K % 128 == 0 && (s == 1 || s == 2 || s == 3 || s == 4 || s == 6 || s == 8 || s == 10);
@@ -633,10 +649,11 @@ static void launch_skinny_ncb(const SkinnyParams &p, hipStream_t st) {
             (void)hipGetDevice(&dev);
             if (dev < 0 || dev >= NH_MAX_DEVICES || !attr_set[dev].load(std::memory_order_acquire)) {
                 hipFuncSetAttribute(reinterpret_cast<const void *>(&skinny_lds_kernel<NCB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, NH_LDS_EXCLUSIVE);
                 if (dev >= 0 && dev < NH_MAX_DEVICES) attr_set[dev].store(true, std::memory_order_release);
             }
-            hipLaunchKernelGGL((skinny_lds_kernel<NCB>), dim3(256), dim3(512), lds, st, p);
+            // `lds` is what the kernel uses; it is given the whole LDS of the CU (NH_LDS_EXCLUSIVE, see there)
+            hipLaunchKernelGGL((skinny_lds_kernel<NCB>), dim3(256), dim3(512), lds_exclusive_bytes(lds), st, p);
         } else if (NCB >= 3 && p.Wt && !p.ln_x && tiles <= LP_MT * 2048) {
             // 33 .. 96 rows: K in phases through the LDS (skinny_ldsp_kernel); as few phases as 144 KiB of LDS allow, balanced
             const int steps = p.K >> 5, spmax = (144 * 1024) / (16 * NCB * 64);
@@ -646,10 +663,11 @@ static void launch_skinny_ncb(const SkinnyParams &p, hipStream_t st) {
             (void)hipGetDevice(&dev);
             if (dev < 0 || dev >= NH_MAX_DEVICES || !attr_set[dev].load(std::memory_order_acquire)) {
                 hipFuncSetAttribute(reinterpret_cast<const void *>(&skinny_ldsp_kernel<NCB>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, NH_LDS_EXCLUSIVE);
                 if (dev >= 0 && dev < NH_MAX_DEVICES) attr_set[dev].store(true, std::memory_order_release);
             }
-            hipLaunchKernelGGL((skinny_ldsp_kernel<NCB>), dim3(256), dim3(512), (size_t)sp * 16 * NCB * 64, st, p, sp);
+            // the kernel uses sp * 16 NCB * 64 bytes; it is given the whole LDS of the CU (NH_LDS_EXCLUSIVE, see there)
+            hipLaunchKernelGGL((skinny_ldsp_kernel<NCB>), dim3(256), dim3(512), lds_exclusive_bytes((size_t)sp * 16 * NCB * 64), st, p, sp);
         } else if constexpr (NCB <= 4) {
             int waves = (tiles + 1) / 2;
             hipLaunchKernelGGL((skinny_gemm_kernel<NCB, 1, 2>), dim3((waves + 1) / 2), dim3(128), 0, st, p);

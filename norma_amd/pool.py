@@ -8,7 +8,9 @@ the five methods below), so the CPU tests drive it with a counting stand-in and 
 
 engine methods used: pool_begin(rows, max_new, per_clip_language), pool_admit(src_row, dst_row, lang),
 pool_step(n) -> flags per row (0 running, 1 / 2 finished, 3 empty), pool_collect(rows) -> [result],
-and the caller's encode(first_clip, n_clips, row0) which must leave clips first .. first + n - 1 encoded in rows row0 ...
+and the caller's encode(first_clip, n_clips, row0, must) which must leave clips first .. first + n - 1 encoded in rows
+row0 ... -- or, when `must` is false, may return False to say "the encoder is busy, ask again" (several pools share one GPU:
+the pool then goes on decoding what it has instead of waiting for the encoder with its rows idle).
 """
 from typing import Callable, List, Optional, Sequence
 
@@ -23,7 +25,7 @@ class DecodePool:
         self.row_steps = 0      # sum over steps of the rows that were busy (what the step kernels' per-row work scales with)
         self.encodes = 0
 
-    def run(self, n_clips: int, encode: Callable[[int, int, int], None], langs: Optional[Sequence[int]] = None,
+    def run(self, n_clips: int, encode: Callable[[int, int, int, bool], Optional[bool]], langs: Optional[Sequence[int]] = None,
             on_result: Optional[Callable[[int, dict], None]] = None) -> List[dict]:
         """Decode clips 0 .. n_clips - 1; returns their results in clip order."""
         e, R = self.e, self.rows
@@ -37,11 +39,11 @@ class DecodePool:
         while next_clip < n_clips or staged or busy:
             if not staged and next_clip < n_clips:
                 n = min(self.staging, n_clips - next_clip)
-                encode(next_clip, n, R)
-                self.encodes += 1
-                staged_first = next_clip
-                staged = list(range(next_clip, next_clip + n))
-                next_clip += n
+                if encode(next_clip, n, R, busy == 0) is not False:   # busy == 0: nothing to decode meanwhile, wait for the encoder
+                    self.encodes += 1
+                    staged_first = next_clip
+                    staged = list(range(next_clip, next_clip + n))
+                    next_clip += n
             for r in range(R):            # admit in clip order into the lowest free rows
                 if not staged:
                     break

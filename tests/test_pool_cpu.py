@@ -12,6 +12,7 @@ class FakeEngine:
     def __init__(self, lengths, prompt=3):
         self.lengths, self.prompt = lengths, prompt
         self.log = []
+        self.busy_every = 0
 
     def pool_begin(self, rows, max_new, per_clip_language):
         self.rows = rows
@@ -21,8 +22,11 @@ class FakeEngine:
         self.lang = [None] * rows
         self.max_concurrent = 0
 
-    def encode(self, first, n, row0):
+    def encode(self, first, n, row0, must):
         assert row0 == self.rows
+        self.asked = getattr(self, "asked", 0) + 1
+        if self.busy_every and not must and self.asked % self.busy_every:
+            return False                   # "the encoder is busy": the pool must go on decoding and ask again
         self.staged = {row0 + i: first + i for i in range(n)}
         self.log.append(("encode", first, n))
 
@@ -58,6 +62,7 @@ def test_every_clip_is_admitted_once_collected_once_and_returned_in_clip_order(r
     N = 57
     lengths = [int(x) for x in rng.choice([3, 10, 40, 41, 120], size=N)]
     e = FakeEngine(lengths)
+    e.busy_every = 3 if rows % 2 == 0 else 0   # half of the cases: an encoder that says "busy" two times out of three
     dp = pool.DecodePool(e, rows=rows, staging=staging, check_every=check)
     seen = []
     res = dp.run(N, e.encode, langs=list(range(1000, 1000 + N)), on_result=lambda c, r: seen.append(c))
