@@ -337,7 +337,11 @@ def worker(args):
                 h.logmel_device_rows(pcm_dev.data_ptr(), n_samples, synth.N_SAMPLES, g * B)
                 h.encode_rows(g * B, B)
                 h.synchronize()
-        return h.decode_greedy(max_new)[:B]
+        out = h.decode_greedy(max_new)
+        under_load.extend(out[k * B:(k + 1) * B] for k in range(groups))
+        return out[:B]
+
+    under_load = []   # every batch result of the pipelined passes: compared with the one-batch-at-a-time result after the timed region
 
     def run_steps(n, max_new, P=P):
         """n steps spread round-robin over the pipelines (each pipeline runs its share sequentially)."""
@@ -353,7 +357,11 @@ def worker(args):
 
         def worker_thread(i):
             for g in units[i::P]:
-                last[i] = step(max_new, hms[i], pipelined=True) if G == 1 else group_step(max_new, hms[i], g)
+                if G == 1:
+                    last[i] = step(max_new, hms[i], pipelined=True)
+                    under_load.append(last[i])
+                else:
+                    last[i] = group_step(max_new, hms[i], g)
         ths = [threading.Thread(target=worker_thread, args=(i,)) for i in range(P)]
         for t in ths:
             t.start()
@@ -390,8 +398,18 @@ def worker(args):
         # one batch at a time, untimed by the contract: the per-phase times (and their roofline fractions below) are taken
         # from this pass, where no other batch shares the GPU; with several batches in flight a phase's wall time
         # includes the kernels of the other batches interleaved with it
-        step(args.max_new_tokens, hm, pipelined=False)
+        alone = step(args.max_new_tokens, hm, pipelined=False)
         barrier()
+        # parity under load: every batch decoded while other batches shared the GPU (warm-up and timed passes) against the same
+        # batch decoded with the GPU to itself -- tokens, avg_logprob and no_speech_prob, bit for bit
+        if under_load and not multilingual:
+            import struct
+            bits = lambda x: struct.pack("<d", x)     # bit patterns: a NaN equals itself here
+            tok_d = sum(1 for batch in under_load for a, b in zip(batch, alone) if a["tokens"] != b["tokens"])
+            lp_d = sum(1 for batch in under_load for a, b in zip(batch, alone) if bits(a["avg_logprob"]) != bits(b["avg_logprob"]))
+            ns_d = sum(1 for batch in under_load for a, b in zip(batch, alone) if bits(a["no_speech_prob"]) != bits(b["no_speech_prob"]))
+            extra["results_under_load"] = {"batches_compared": len(under_load), "sequences_compared": len(under_load) * B,
+                                           "differing_from_the_batch_decoded_alone": {"tokens": tok_d, "avg_logprob": lp_d, "no_speech_prob": ns_d}}
         if not args.no_single_extra:
             n1 = 3
             t1 = time.perf_counter()

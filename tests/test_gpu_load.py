@@ -1,0 +1,122 @@
+"""GPU: results under LOAD -- several contexts in flight on one GPU, every result compared with what the same clip gives with
+the GPU to itself.
+
+Why this file exists (r03): with three decode pools in flight a clip's avg_logprob came out different in its low digits now and
+then.  The first stage to differ was the log-mel: a log-mel workgroup (37 KB of LDS, 4 waves) that shared its CU with a
+workgroup of ANOTHER context's logits kernel -- activations staged in LDS, every MFMA fed by a `ds_read_b128` -- computed wrong
+spectra in 1 to 250 frames of a clip; LDS allocations and barriers of co-resident workgroups do stay apart (tools/ldsprobe.hip),
+and it takes the LDS read feeding the MFMA: LDS reads without MFMAs, or MFMAs fed from registers, leave the neighbour alone
+(bisect: tools/dbg/stress_mel.py, k_decode.hip at NH_LDS_EXCLUSIVE).  Those kernels now take the whole LDS of their CU, so no
+LDS-using workgroup runs beside them.  Without that, the first test below sees 150-190 wrong clip-mels in 3200.
+
+The reference has nothing comparable (one stream at a time, src/lib.rs:462-464); what is at stake is the invariant every parity
+test relies on: a clip's result does not depend on what else the GPU is doing."""
+import threading
+
+import numpy as np
+import pytest
+
+import common
+from norma_amd import config, pool, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n_other, max_batch_other):
+    import sys
+    sys.path.insert(0, common.ROOT)
+    import bench
+    import test_gpu_pool as T
+    from norma_amd import hip
+    name = "distil-large-v3"
+    cfg = config.preset(name)
+    tk = common.tokens_for(name)
+    hm = T._varlen_weights(cfg, tk, eot_steps=bench.VARLEN_EOT_STEPS, text_steps=bench.VARLEN_TEXT_STEPS, n_calib=16, max_batch=32, seed=77)
+    others = [hip.HipWhisper(cfg, device=0, max_batch=max_batch_other, share_with=hm) for _ in range(n_other)]
+    for h in others:
+        h.set_tokens(tk, tk.en, tk.transcribe)
+    return cfg, tk, hm, others
+
+
+def test_log_mel_is_bit_exact_beside_64_row_decode_steps_of_other_contexts():
+    cfg, tk, hm, others = _setup(2, 96)
+    clips = np.stack([synth.synth_pcm(k) for k in range(32)])
+    hm.logmel_array(clips)
+    ref = np.stack([hm.get_mel(b) for b in range(32)])
+    stop = threading.Event()
+    errs = []
+
+    def traffic(h):     # all 64 rows admitted once and never collected: every step launches the whole 64-row kernel set
+        try:
+            h.pool_begin(64, 0, False)
+            h.logmel_array_rows(clips, 64); h.encode_rows(64, 32); h.synchronize()
+            for r in range(64):
+                h.pool_admit(64 + (r % 32), r)
+            while not stop.is_set():
+                h.pool_step(16)
+        except BaseException as e:   # noqa: BLE001 -- re-raised below
+            errs.append(e); stop.set()
+    ths = [threading.Thread(target=traffic, args=(h,)) for h in others]
+    for t in ths:
+        t.start()
+    bad, rounds = [], 50
+    try:
+        for r in range(rounds):
+            hm.logmel_array(clips)
+            for b in range(32):
+                m = hm.get_mel(b)
+                if not np.array_equal(m, ref[b]):
+                    bad.append((r, b, float(np.abs(m - ref[b]).max())))
+    finally:
+        stop.set()
+        for t in ths:
+            t.join()
+    assert not errs, errs
+    assert others[0].timings()["decode_steps"] >= 200      # the other contexts really were decoding all the while
+    assert not bad, (len(bad), bad[:8])
+    for h in others:
+        h.close()
+    hm.close()
+
+
+def test_three_decode_pools_in_flight_give_every_clip_the_result_it_has_alone():
+    cfg, tk, hm, pools_ = _setup(3, 96)
+    JOB, PER = 64, 96
+    clips = np.stack([synth.synth_pcm(k) for k in range(JOB)])
+    want = []
+    for g in range(0, JOB, 32):
+        hm.logmel_array(np.ascontiguousarray(clips[g:g + 32])); hm.encode()
+        want.extend(hm.decode_greedy())
+    lock = threading.Lock()
+    bad, errs = [], []
+
+    def one(i):
+        try:
+            hp, first = pools_[i], i * PER
+
+            def encode(f, n, row0, must):
+                if not lock.acquire(blocking=must):   # one encoder submission at a time; a pool with rows decoding does not wait
+                    return False
+                try:
+                    ids = [(first + f + k) % JOB for k in range(n)]
+                    hp.logmel_array_rows(np.ascontiguousarray(clips[ids]), row0); hp.encode_rows(row0, n); hp.synchronize()
+                finally:
+                    lock.release()
+                return True
+            got = pool.DecodePool(hp, rows=64, staging=32, check_every=16).run(PER, encode)
+            for j, g in enumerate(got):
+                w = want[(first + j) % JOB]
+                if g["tokens"] != w["tokens"] or g["avg_logprob"] != w["avg_logprob"] or g["no_speech_prob"] != w["no_speech_prob"]:
+                    bad.append((i, j, g["tokens"] == w["tokens"], g["avg_logprob"] - w["avg_logprob"]))
+        except BaseException as e:   # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=one, args=(i,)) for i in range(3)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    assert not bad, (len(bad), bad[:8])
+    for h in pools_:
+        h.close()
+    hm.close()
