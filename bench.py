@@ -88,6 +88,7 @@ def parse_args(argv=None):
     ap.add_argument("--balance", action="store_true",
                     help="workload varlen: `value` is the length-bucketed / partition_balanced pass (default: arrival order)")
     ap.add_argument("--pool-contexts", type=int, default=2, help="workload varlen: decode pools in flight per GPU")
+    ap.add_argument("--pool-check-every", type=int, default=16, help="workload varlen: decode steps between two looks at the rows' done flags")
     ap.add_argument("--pool", action="store_true",
                     help="workload varlen: `value` is the decode-pool pass (norma_amd/pool.py; default: arrival-order lockstep batches)")
     ap.add_argument("--dry-run", action="store_true",
@@ -671,7 +672,7 @@ def worker_varlen(args, cfg, tk, world, rank, local_rank, dev, backend, gather_d
             try:
                 torch.cuda.set_device(dev)
                 hmp, stg, (p0, pc) = hmps[i], stages[i], parts[i]
-                dp = pool.DecodePool(hmp, rows=POOL_ROWS, staging=BMAX, check_every=16)
+                dp = pool.DecodePool(hmp, rows=POOL_ROWS, staging=BMAX, check_every=args.pool_check_every)
 
                 def encode(f, n, row0, must):
                     # one encoder submission at a time on the GPU; the decode steps of the other pools run beside it, and a pool
@@ -738,7 +739,7 @@ def worker_varlen(args, cfg, tk, world, rank, local_rank, dev, backend, gather_d
         sb = summary(balanced, lambda mine: shard.length_buckets(mine, steps, BMAX), t_b)
         need_stream = args.steps * sum(steps)
         sp = {"xrt": stream * 30.0 / t_p, "ms_per_job": t_p * 1e3 / args.steps, "stream_chunks": stream, "pools_per_gpu": NPOOL, "decode_rows": POOL_ROWS,
-              "staging_rows": BMAX, "check_every": 16, "row_steps_run": pool_stats[0], "row_steps_needed": need_stream,
+              "staging_rows": BMAX, "check_every": args.pool_check_every, "row_steps_run": pool_stats[0], "row_steps_needed": need_stream,
               "wasted_row_step_frac": 1.0 - need_stream / max(pool_stats[0], 1.0), "decode_steps_launched": pool_stats[1],
               "encoder_submissions": pool_stats[2], "same_tokens_and_logprobs_as_lockstep": pool_stats[3] == world,
               "mismatches_rank0": pool_bad[:12], "mismatch_indices_rank0": [b[0] for b in pool_bad], "n_mismatches_rank0": len(pool_bad)}
