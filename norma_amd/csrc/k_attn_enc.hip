@@ -38,7 +38,11 @@
 __device__ __forceinline__ int swap23(int x) { return (x & ~12) | ((x & 4) << 1) | ((x & 8) >> 1); }
 
 #ifndef ENC_ATTN_MINWAVES
+#ifdef ENC_ATTN_PIPE
+#define ENC_ATTN_MINWAVES 2   // one 8-wave workgroup per CU: 256 VGPRs for two tiles of scores in flight
+#else
 #define ENC_ATTN_MINWAVES 4   // two 8-wave workgroups per CU need <= 128 VGPRs
+#endif
 #endif
 __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? ENC_ATTN_MINWAVES : 1)) void ENC_ATTN_KERNEL(const half_t *__restrict__ q, const half_t *__restrict__ k,
                                                          long ld, const half_t *__restrict__ vt,
@@ -71,24 +75,39 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? ENC_ATTN_MINWAVES : 1)) void E
     }
     u32x4 rk[NSLOT], rv[NSLOT];
     const bool stager = NTHR <= 512 || tid < 512;
-    auto load_tile = [&](int t) {
+    auto load_k = [&](int t) {
         if (!stager) return;
 #pragma unroll
         for (int i = 0; i < NSLOT; i++) {
             int key = t * KT + krow_off[i]; if (key >= S) key = S - 1;
             rk[i] = *reinterpret_cast<const u32x4 *>(kg[i] + (long)key * ld);
-            rv[i] = *reinterpret_cast<const u32x4 *>(vg[i] + t * KT);
         }
     };
-    auto store_tile = [&](int buf) {
+    auto load_v = [&](int t) {
+        if (!stager) return;
+#pragma unroll
+        for (int i = 0; i < NSLOT; i++) rv[i] = *reinterpret_cast<const u32x4 *>(vg[i] + t * KT);
+    };
+    // LDS: K tiles of buffer 0 / 1 at 0 / 2 TILE_B, V^T tiles at TILE_B / 3 TILE_B
+    auto store_k = [&](int buf) {
         if (!stager) return;
         u32x4 *lk = reinterpret_cast<u32x4 *>(smem + buf * 2 * TILE_B);
+#pragma unroll
+        for (int i = 0; i < NSLOT; i++) lk[tid + NTHR * i] = rk[i];
+    };
+    auto store_v = [&](int buf) {
+        if (!stager) return;
         u32x4 *lv = reinterpret_cast<u32x4 *>(smem + buf * 2 * TILE_B + TILE_B);
 #pragma unroll
-        for (int i = 0; i < NSLOT; i++) { lk[tid + NTHR * i] = rk[i]; lv[tid + NTHR * i] = rv[i]; }
+        for (int i = 0; i < NSLOT; i++) lv[tid + NTHR * i] = rv[i];
     };
+    auto load_tile = [&](int t) { load_k(t); load_v(t); };
+    auto store_tile = [&](int buf) { store_k(buf); store_v(buf); };
     load_tile(0);
     store_tile(0);
+#ifdef ENC_ATTN_PIPE
+    if (nT > 1) { load_k(1); store_k(1); }
+#endif
     __syncthreads();
 
     // fragment byte offsets inside a tile (before adding the per-step chunk xor)
@@ -119,7 +138,7 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? ENC_ATTN_MINWAVES : 1)) void E
 
     f32x16 s0, s1;   // scores of the tile in flight: written by qk_phase, consumed by sv_phase
     // first half of a tile: S'^T = K (cQ)^T - m_ref (10 MFMAs)
-    auto qk_phase = [&](const char *tk) {
+    auto qk_phase = [&](const char *tk, f32x16 &s0, f32x16 &s1) {
         {
             // the first k-step takes a literal zero accumulator (an inline constant of the MFMA, not 32 v_mov per tile)
             half8 k0 = *reinterpret_cast<const half8 *>(tk + offK0);
@@ -139,7 +158,7 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? ENC_ATTN_MINWAVES : 1)) void E
         s1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kx, qx, s1, 0, 0, 0);
     };
     // second half: mask, maximum / rare rebase, exp2, row sum, P -> fp16, O^T += V^T P^T (8 MFMAs)
-    auto sv_phase = [&](int t, const char *tv) {
+    auto sm_head = [&](int t) {
         if (t * KT + KT > S) {  // last, partial tile: mask keys >= S
 #pragma unroll
             for (int i = 0; i < 16; i++) {
@@ -172,6 +191,8 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? ENC_ATTN_MINWAVES : 1)) void E
             qx[0] = hh == 0 ? hi : (half_t)0.f;
             qx[1] = hh == 0 ? lo : (half_t)0.f;
         }
+    };
+    auto sm_body = [&](const char *tv) {
         float ps = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; i++) {
@@ -201,17 +222,46 @@ __global__ __launch_bounds__(NTHR, (NTHR <= 512 ? ENC_ATTN_MINWAVES : 1)) void E
     };
     // (r03, tools/abench, one box: a schedule in which waves 4-7 run half a tile behind waves 0-3 -- two barriers per tile, one
     // half multiplying K Q^T while the other does softmax + P V -- measured 640-670 us against 446-454 for this loop; four
-    // independent max / sum chains, v_dot2_f32_f16 row sums and s_setprio around the MFMA clusters all within +-1.5 %.)
+    // independent max / sum chains, v_dot2_f32_f16 row sums and s_setprio around the MFMA clusters all within +-1.5 %.  Later in
+    // r03: workgroups of 4 and 16 waves 856 / 501 us; the second workgroup of a CU started 1000-3000 cycles late: no change; the
+    // software-pipelined form below (ENC_ATTN_PIPE: one 8-wave workgroup per CU, 161 VGPRs, K Q^T of tile t + 1 issued between
+    // the exponentials of tile t) 577-609 us: two waves per SIMD do not cover the dependent-MFMA and LDS latencies that four do.)
+#ifndef ENC_ATTN_PIPE
     int cur = 0;
     for (int t = 0; t < nT; t++) {
         const bool more = (t + 1 < nT);
         if (more) load_tile(t + 1);
-        qk_phase(smem + cur * 2 * TILE_B);
-        sv_phase(t, smem + cur * 2 * TILE_B + TILE_B);
+        qk_phase(smem + cur * 2 * TILE_B, s0, s1);
+        sm_head(t);
+        sm_body(smem + cur * 2 * TILE_B + TILE_B);
         if (more) store_tile(cur ^ 1);
         __syncthreads();
         cur ^= 1;
     }
+#else
+    // Software-pipelined form: the matrix pipe and the vector ALU of a SIMD work at the same time only when ONE instruction
+    // stream offers both (waves do not fill each other's gaps here: 576 MFMA + 540 VALU cycles per wave-tile took 1090), so
+    // the K Q^T products of tile t + 1 are issued between the exponentials of tile t.  At the top of iteration t the LDS holds
+    // K(t + 1) and V^T(t); K(t + 2) and V^T(t + 1) are fetched during the iteration into the buffers of K(t) and V^T(t - 1).
+    f32x16 n0, n1;
+    qk_phase(smem, s0, s1);
+    for (int t = 0; t < nT; t++) {
+        if (t + 2 < nT) load_k(t + 2);
+        if (t + 1 < nT) load_v(t + 1);
+        sm_head(t);                                                   // mask, maximum, (rare) rebase: moves qx before it is used below
+        qk_phase(smem + ((t + 1) & 1) * 2 * TILE_B, n0, n1);         // tile t + 1 (after the last tile: a stale buffer, result unused)
+        sm_body(smem + (t & 1) * 2 * TILE_B + TILE_B);               // exp2, row sums, P, O^T += V^T P^T of tile t
+#pragma unroll
+        for (int i = 0; i < 18; i++) {                                // one MFMA, then its share of the 100-odd vector instructions
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, ENC_ATTN_PIPE, 0);
+        }
+        if (t + 2 < nT) store_k(t & 1);
+        if (t + 1 < nT) store_v((t + 1) & 1);
+        __syncthreads();
+        s0 = n0; s1 = n1;
+    }
+#endif
     const float l_tot = l_run + __shfl_xor(l_run, 32);
     const float inv = 1.0f / l_tot;
     const int qrow = q0 + r;
