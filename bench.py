@@ -89,6 +89,8 @@ def parse_args(argv=None):
                     help="workload varlen: `value` is the length-bucketed / partition_balanced pass (default: arrival order)")
     ap.add_argument("--pool-contexts", type=int, default=2, help="workload varlen: decode pools in flight per GPU")
     ap.add_argument("--pool-check-every", type=int, default=16, help="workload varlen: decode steps between two looks at the rows' done flags")
+    ap.add_argument("--pool-encoders", type=int, default=2, help="workload varlen: encoder contexts feeding ONE decoding context (0: skip that pass)")
+    ap.add_argument("--pool-fed", action="store_true", help="workload varlen: `value` is the pass with one decoding context fed by --pool-encoders encoder contexts")
     ap.add_argument("--pool", action="store_true",
                     help="workload varlen: `value` is the decode-pool pass (norma_amd/pool.py; default: arrival-order lockstep batches)")
     ap.add_argument("--dry-run", action="store_true",
@@ -717,6 +719,54 @@ def worker_varlen(args, cfg, tk, world, rank, local_rank, dev, backend, gather_d
         t_p = float(t.item())
     pool_same = all(r["tokens"] == res_a[(s0 + i) % job]["tokens"] and r["avg_logprob"] == res_a[(s0 + i) % job]["avg_logprob"]
                     for i, r in enumerate(res_p))
+    # (d) one decoding context fed by encoder contexts (nh_pool_admit_from, pool.FedDecodePool): the pool's stream never runs an encoder
+    fed = None
+    if args.pool_encoders > 0:
+        FROWS = 64
+        hf = hip.HipWhisper(cfg, device=local_rank, max_batch=FROWS + 1, share_with=hm)
+        hf.set_tokens(tk, tk.en, tk.transcribe)
+        hes = [hip.HipWhisper(cfg, device=local_rank, max_batch=BMAX, share_with=hm) for _ in range(args.pool_encoders)]
+        for h in hes:
+            h.set_tokens(tk, tk.en, tk.transcribe)
+        estage = [torch.empty((BMAX, synth.N_SAMPLES), dtype=torch.float32, device=dev) for _ in hes]
+
+        def fed_pass(first, count):
+            fp = pool.FedDecodePool(hf, hes, rows=FROWS, batch=BMAX, check_every=args.pool_check_every)
+
+            def encode(i, f, n):
+                torch.cuda.set_device(dev)
+                c0 = (first + f) % job
+                if c0 + n <= job:       # the clips lie next to each other in HBM: no staging copy
+                    ptr = pcm_all[c0].data_ptr()
+                else:
+                    idx = torch.tensor([(first + f + k) % job for k in range(n)], dtype=torch.long, device=dev)
+                    torch.index_select(pcm_all, 0, idx, out=estage[i][:n])
+                    torch.cuda.synchronize()
+                    ptr = estage[i].data_ptr()
+                hes[i].logmel_device(ptr, [synth.N_SAMPLES] * n, synth.N_SAMPLES)
+                hes[i].encode()
+                hes[i].synchronize()
+            return fp.run(count, encode), fp
+        fed_pass(0, min(job, cnt)); barrier()
+        t0 = time.perf_counter()
+        res_f, fp = fed_pass(s0, cnt)
+        if world > 1:
+            shard.gather_results(res_f, stream, C, device=gather_dev)
+        barrier()
+        t_f = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([t_f], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            t_f = float(t.item())
+        fed_same = all(r["tokens"] == res_a[(s0 + i) % job]["tokens"] and r["avg_logprob"] == res_a[(s0 + i) % job]["avg_logprob"]
+                       for i, r in enumerate(res_f))
+        fst = torch.tensor([fp.row_steps, fp.steps, fp.encodes, int(fed_same)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(fst, op=dist.ReduceOp.SUM)
+        fed = (t_f, [float(v) for v in fst.tolist()], FROWS)
+        hf.close()
+        for h in hes:
+            h.close()
     pool_bad = [(s0 + i, r["tokens"] == res_a[(s0 + i) % job]["tokens"], r["avg_logprob"] - res_a[(s0 + i) % job]["avg_logprob"])
                 for i, r in enumerate(res_p) if r["tokens"] != res_a[(s0 + i) % job]["tokens"] or r["avg_logprob"] != res_a[(s0 + i) % job]["avg_logprob"]]
     pool_stats = torch.tensor([dp.row_steps, dp.steps, dp.encodes, int(pool_same)], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
@@ -743,14 +793,21 @@ def worker_varlen(args, cfg, tk, world, rank, local_rank, dev, backend, gather_d
               "wasted_row_step_frac": 1.0 - need_stream / max(pool_stats[0], 1.0), "decode_steps_launched": pool_stats[1],
               "encoder_submissions": pool_stats[2], "same_tokens_and_logprobs_as_lockstep": pool_stats[3] == world,
               "mismatches_rank0": pool_bad[:12], "mismatch_indices_rank0": [b[0] for b in pool_bad], "n_mismatches_rank0": len(pool_bad)}
-        t_val = t_p / args.steps if args.pool else (t_b if args.balance else t_a)
+        sf = None
+        if fed is not None:
+            sf = {"xrt": stream * 30.0 / fed[0], "ms_per_job": fed[0] * 1e3 / args.steps, "stream_chunks": stream, "decode_rows": fed[2],
+                  "encoder_contexts": args.pool_encoders, "row_steps_run": fed[1][0], "row_steps_needed": need_stream,
+                  "wasted_row_step_frac": 1.0 - need_stream / max(fed[1][0], 1.0), "decode_steps_launched": fed[1][1],
+                  "encoder_submissions": fed[1][2], "same_tokens_and_logprobs_as_lockstep": fed[1][3] == world}
+        t_val = (fed[0] / args.steps if (args.pool_fed and fed is not None) else t_p / args.steps if args.pool else (t_b if args.balance else t_a))
         gemm_tflops = tm["gemm_flops"] / (tm["gemm_ms"] * 1e-3) / 1e12 if tm["gemm_ms"] > 0 else 0.0
         out = {"metric": "audio-sec/wall-sec (xRT) distil-large-v3 fp16, variable decode lengths", "value": job * 30.0 / t_val,
                "unit": "audio-sec/wall-sec", "n_gpus": world, "steps": args.steps, "warmup": 1, "ms_per_step": t_val * 1e3,
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
                "config": {"workload": f"{job} x 30 s chunks whose transcripts end at different steps (audio-decided eot votes at text "
                                       f"steps {VARLEN_EOT_STEPS}), batches of <= {BMAX}, " +
-                                      ("one stream through a 64-row decode pool (sequences join and leave a running decode)" if args.pool else
+                                      ("one stream through a 64-row decode pool fed by encoder contexts of the same weight set" if args.pool_fed else
+                                       "one stream through a 64-row decode pool (sequences join and leave a running decode)" if args.pool else
                                        "length-bucketed batches dealt with partition_balanced" if args.balance else "arrival-order batches"),
                           "name": "varlen", "chunks": job, "batch_per_gpu": BMAX, "parallelism": f"chunk-dp{world}"},
                "roofline": {"bound": "mfma", "kernel": "gemm256_f16_kernel", "achieved": gemm_tflops, "peak": MFMA_PEAK_TFLOPS,
@@ -758,7 +815,8 @@ def worker_varlen(args, cfg, tk, world, rank, local_rank, dev, backend, gather_d
                "cpu_baseline": None,
                "extra": {"decode_steps": {"min": min(steps), "median": int(np.median(steps)), "mean": float(np.mean(steps)), "max": max(steps),
                                           "histogram": {str(v): steps.count(v) for v in sorted(set(steps))}},
-                         "arrival_order": sa, "length_bucketed": sb, "decode_pool": sp, "same_tokens_both_ways": identical}}
+                         "arrival_order": sa, "length_bucketed": sb, "decode_pool": sp, "decode_pool_fed_by_encoder_contexts": sf,
+                         "same_tokens_both_ways": identical}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

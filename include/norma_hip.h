@@ -177,6 +177,11 @@ int nh_pool_begin(nh_ctx *ctx, int rows, int max_new_tokens, int per_clip_langua
 /* The clip encoded at staging row src_row (>= rows) starts decoding in the free row dst_row (< rows): its cross K/V move
  * (device-to-device, 4 * S * d_model bytes per decoder layer), its decode state starts over.  Asynchronous. */
 int nh_pool_admit(nh_ctx *ctx, int src_row, int dst_row, int32_t lang);
+/* The same, the clip coming from row src_row of ANOTHER context of the same weight set (nh_create_shared) that ran
+ * nh_logmel* + nh_encode / nh_encode_rows on it: one context decodes without ever stalling for an encoder submission while others
+ * encode.  Ordered on the device (the copy waits for that encoder, that context's next encoder submission waits for the copy); on
+ * the host the caller keeps this call apart from calls ON `enc` that change its rows (nh_logmel*, nh_encode*). */
+int nh_pool_admit_from(nh_ctx *ctx, nh_ctx *enc, int src_row, int dst_row, int32_t lang);
 /* n_steps decode steps (one token per busy, unfinished row each), then done_out[rows]: 0 running, 1 finished, 2 finished by
  * the no-speech exit, 3 empty.  Returns when the steps have run. */
 int nh_pool_step(nh_ctx *ctx, int n_steps, int32_t *done_out);

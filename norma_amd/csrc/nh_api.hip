@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <memory>
+#include <algorithm>
 #include <mutex>
 #include <set>
 #include <string>
@@ -70,6 +71,12 @@ struct nh_ctx {
     hipStream_t st = nullptr;   // the context's stream: log-mel, encoder, cross K/V, decode loop
     hipStream_t sd = nullptr;   // alias of st (the decode loop's launches are written against sd; see build_context)
     hipEvent_t enc_done = nullptr;
+    // nh_pool_admit_from: decode pools of OTHER contexts copy cross K/V out of this context's rows on THEIR streams; the next
+    // encoder submission here must not overwrite those rows before the copies have run
+    struct EventBox { hipEvent_t e = nullptr; ~EventBox() { if (e) hipEventDestroy(e); } };
+    std::shared_ptr<EventBox> kv_copied;       // recorded on this context's stream after it copied K/V out of another context
+    std::mutex readers_mu;
+    std::vector<std::shared_ptr<EventBox>> kv_readers;   // kv_copied of the pools that read this context's K/V since its last encode (kept alive here)
     nh_config c{};
     int B = 1;
     std::string err;
@@ -323,7 +330,8 @@ static int build_context(std::shared_ptr<nh_model> mdl, int max_batch, nh_ctx **
     // 6326, three 4782, decode stream created first 4785, ONE stream per context 6358).  Encoder and decode of one
     // context are sequential anyway; with one queue per context three contexts plus the null stream fit the four pipes.
     if (hipStreamCreateWithFlags(&ctx->st, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->enc_done, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->enc_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&(ctx->kv_copied = std::make_shared<nh_ctx::EventBox>())->e, hipEventDisableTiming) != hipSuccess) {
         ctx->err = "hipStreamCreateWithFlags failed"; return bail(NH_ERR_HIP);
     }
     ctx->sd = ctx->st;
@@ -803,6 +811,11 @@ static int encode_rows(nh_ctx *ctx, int row0, int B) {
     half_t *const xn = ctx->xn + r0 * S * d, *const q = ctx->q + r0 * S * d, *const k = ctx->k + r0 * S * d, *const att = ctx->att + r0 * S * d;
     half_t *const vt = ctx->vt + r0 * d * NH_SP, *const hid = ctx->hid + r0 * S * 4 * d, *const xa16 = ctx->xa16 + r0 * S * d;
     ctx->gemm_ev_used = 0; ctx->gemm_flops_acc = 0.0;
+    {   // decode pools of other contexts that are still copying K/V out of these rows (nh_pool_admit_from) go first
+        std::lock_guard<std::mutex> lk(ctx->readers_mu);
+        for (auto &e : ctx->kv_readers) HIPCHK(hipStreamWaitEvent(ctx->st, e->e, 0));
+        ctx->kv_readers.clear();
+    }
     HIPCHK(hipEventRecord(ctx->ev[2], ctx->st));
     {   // conv1 + GELU: A rows overlap (lda = 128, K = 3 * 128) inside the zero-framed mel image
         GemmParams p{};
@@ -1085,10 +1098,7 @@ extern "C" int nh_pool_begin(nh_ctx *ctx, int rows, int max_new_tokens, int per_
     return NH_OK;
 }
 
-extern "C" int nh_pool_admit(nh_ctx *ctx, int src_row, int dst_row, int32_t lang) {
-    if (!ctx) return NH_ERR_INVALID;
-    if (ctx->pool_rows < 1) return ctx->fail(NH_ERR_STATE, "nh_pool_admit: no decode pool (nh_pool_begin)");
-    if (!ctx->have_enc || src_row < ctx->pool_rows || src_row >= ctx->cur_batch) return ctx->fail(NH_ERR_STATE, "nh_pool_admit: src_row is not an encoded staging row (nh_encode_rows)");
+static int pool_admit_impl(nh_ctx *ctx, nh_ctx *src, int src_row, int dst_row, int32_t lang) {
     if (dst_row < 0 || dst_row >= ctx->pool_rows || ctx->pool_busy[dst_row]) return ctx->fail(NH_ERR_INVALID, "nh_pool_admit: dst_row is not a free row of the pool");
     const int P = ctx->pool_prompt;
     if (!ctx->pool_per_clip_language && lang >= 0) return ctx->fail(NH_ERR_INVALID, "nh_pool_admit: the pool was begun without per-clip languages");
@@ -1096,9 +1106,16 @@ extern "C" int nh_pool_admit(nh_ctx *ctx, int src_row, int dst_row, int32_t lang
     if (P == 3 && (lg < 0 || lg >= ctx->c.vocab_size)) return ctx->fail(NH_ERR_INVALID, "nh_pool_admit: language token outside the vocabulary");
     hipSetDevice(ctx->dev);
     const size_t per = (size_t)ctx->S * ctx->c.d_model;  // cross K / V of one clip and layer, head-major [h][S][64]
-    for (auto &L : ctx->dec) {
-        HIPCHK(hipMemcpyAsync(L.ck + per * dst_row, L.ck + per * src_row, per * sizeof(half_t), hipMemcpyDeviceToDevice, ctx->sd));
-        HIPCHK(hipMemcpyAsync(L.cv + per * dst_row, L.cv + per * src_row, per * sizeof(half_t), hipMemcpyDeviceToDevice, ctx->sd));
+    if (src != ctx) HIPCHK(hipStreamWaitEvent(ctx->sd, src->enc_done, 0));   // the other context's encoder ran on its own stream
+    for (size_t l = 0; l < ctx->dec.size(); l++) {
+        auto &L = ctx->dec[l]; auto &Ls = src->dec[l];
+        HIPCHK(hipMemcpyAsync(L.ck + per * dst_row, Ls.ck + per * src_row, per * sizeof(half_t), hipMemcpyDeviceToDevice, ctx->sd));
+        HIPCHK(hipMemcpyAsync(L.cv + per * dst_row, Ls.cv + per * src_row, per * sizeof(half_t), hipMemcpyDeviceToDevice, ctx->sd));
+    }
+    if (src != ctx) {   // src's next encoder submission waits for these copies
+        HIPCHK(hipEventRecord(ctx->kv_copied->e, ctx->sd));
+        std::lock_guard<std::mutex> lk(src->readers_mu);
+        if (std::find(src->kv_readers.begin(), src->kv_readers.end(), ctx->kv_copied) == src->kv_readers.end()) src->kv_readers.push_back(ctx->kv_copied);
     }
     // model.rs:285-289: prompt = [sot, lang?, task]
     launch_pool_admit(ctx->ds, ctx->d_pos, ctx->ltick, dst_row, ctx->c.max_target_positions, ctx->tk.sot, P == 3 ? lg : ctx->tk.task,
@@ -1106,6 +1123,25 @@ extern "C" int nh_pool_admit(nh_ctx *ctx, int src_row, int dst_row, int32_t lang
     HIPCHK(hipGetLastError());
     ctx->pool_busy[dst_row] = 1;
     return NH_OK;
+}
+
+extern "C" int nh_pool_admit(nh_ctx *ctx, int src_row, int dst_row, int32_t lang) {
+    if (!ctx) return NH_ERR_INVALID;
+    if (ctx->pool_rows < 1) return ctx->fail(NH_ERR_STATE, "nh_pool_admit: no decode pool (nh_pool_begin)");
+    if (!ctx->have_enc || src_row < ctx->pool_rows || src_row >= ctx->cur_batch) return ctx->fail(NH_ERR_STATE, "nh_pool_admit: src_row is not an encoded staging row (nh_encode_rows)");
+    return pool_admit_impl(ctx, ctx, src_row, dst_row, lang);
+}
+
+extern "C" int nh_pool_admit_from(nh_ctx *ctx, nh_ctx *enc, int src_row, int dst_row, int32_t lang) {
+    if (!ctx || !enc) return ctx ? ctx->fail(NH_ERR_INVALID, "nh_pool_admit_from: bad arguments") : NH_ERR_INVALID;
+    if (enc == ctx) return nh_pool_admit(ctx, src_row, dst_row, lang);
+    if (ctx->pool_rows < 1) return ctx->fail(NH_ERR_STATE, "nh_pool_admit_from: no decode pool (nh_pool_begin)");
+    if (enc->mdl != ctx->mdl || enc->dev != ctx->dev) return ctx->fail(NH_ERR_INVALID, "nh_pool_admit_from: the encoder context must share this context's weights (nh_create_shared)");
+    if (enc->pool_rows > 0) return ctx->fail(NH_ERR_INVALID, "nh_pool_admit_from: the encoder context runs a pool of its own");
+    if (!enc->have_enc || src_row < 0 || src_row >= enc->cur_batch) return ctx->fail(NH_ERR_STATE, "nh_pool_admit_from: src_row is not an encoded row of the encoder context (nh_encode / nh_encode_rows)");
+    if (ctx->frames < 0) { ctx->frames = enc->frames; ctx->S = enc->S; }   // the pool's clip length is its first clip's
+    else if (enc->frames != ctx->frames) return ctx->fail(NH_ERR_INVALID, "all clips of one decode pool must produce the same number of mel frames");
+    return pool_admit_impl(ctx, enc, src_row, dst_row, lang);
 }
 
 static int capture_step_graphs(nh_ctx *ctx, int B, int max_new_tokens, int P, int mode) {

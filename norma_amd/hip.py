@@ -98,6 +98,7 @@ def load_library() -> C.CDLL:
     L.nh_encode_rows.argtypes = [vp, C.c_int, C.c_int]
     L.nh_pool_begin.argtypes = [vp, C.c_int, C.c_int, C.c_int]
     L.nh_pool_admit.argtypes = [vp, C.c_int, C.c_int, C.c_int32]
+    L.nh_pool_admit_from.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int32]
     L.nh_pool_step.argtypes = [vp, C.c_int, ip]
     L.nh_pool_collect.argtypes = [vp, ip, C.c_int, ip, C.POINTER(NhDecodeResult)]
     L.nh_logmel_samples.argtypes = [vp, vp, C.c_int, ip, C.c_int64, C.c_int]
@@ -263,6 +264,10 @@ class HipWhisper:
 
     def pool_admit(self, src_row: int, dst_row: int, lang: int = -1):
         self._chk(self.L.nh_pool_admit(self._h, src_row, dst_row, lang))
+
+    def pool_admit_from(self, enc: "HipWhisper", src_row: int, dst_row: int, lang: int = -1):
+        """the clip encoded in row src_row of ANOTHER context of the same weight set joins this context's pool"""
+        self._chk(self.L.nh_pool_admit_from(self._h, enc._h, src_row, dst_row, lang))
 
     def pool_step(self, n_steps: int) -> np.ndarray:
         """n_steps tokens for every busy row; returns the rows' flags (0 running, 1 finished, 2 no-speech exit, 3 empty)."""

@@ -87,6 +87,45 @@ def test_clips_through_the_pool_give_bit_for_bit_what_they_give_in_a_lockstep_ba
     hm.close(); hp.close()
 
 
+@pytest.mark.parametrize("rows,batch,n_enc", [(6, 4, 2), (16, 8, 1), (5, 7, 3)])
+def test_a_pool_fed_by_encoder_contexts_of_the_same_weight_set_gives_the_lockstep_results(rows, batch, n_enc):
+    """nh_pool_admit_from: the decoding context never runs an encoder; encoder contexts (nh_create_shared) encode `batch` clips at a
+    time on their own streams and threads, their cross K/V are moved into free rows (device-side ordering by events both ways:
+    the copy waits for that encoder, the context's next encoder submission waits for the copy)."""
+    hip = _hip()
+    name, N = "test-d128", 31
+    cfg = config.preset(name)
+    tk = common.tokens_for(name)
+    hm = _varlen_weights(cfg, tk, eot_steps=[2, 5, 9, 14, 22], text_steps=40, n_calib=8, max_batch=N)
+    clips = np.stack([synth.synth_pcm(k) for k in range(N)])
+    hm.logmel_array(clips); hm.encode()
+    want = hm.decode_greedy()
+    hp = hip.HipWhisper(cfg, device=0, max_batch=rows + 1, share_with=hm)
+    encs = [hip.HipWhisper(cfg, device=0, max_batch=batch, share_with=hm) for _ in range(n_enc)]
+    for h in [hp] + encs:
+        h.set_tokens(tk, tk.en, tk.transcribe)
+
+    def encode(i, first, n):
+        encs[i].logmel_array(np.ascontiguousarray(clips[first:first + n])); encs[i].encode()
+    fp = pool.FedDecodePool(hp, encs, rows=rows, batch=batch, check_every=3)
+    got = fp.run(N, encode)
+    bad = [i for i, (g, w) in enumerate(zip(got, want)) if not _same(g, w)]
+    assert not bad, bad
+    assert fp.encodes == -(-N // batch)
+    # refusals: a context with other weights, a row that is not encoded, an encoder context that runs a pool itself
+    other = common.build_hip(cfg, tk, max_batch=2)
+    other.logmel_array(clips[:2]); other.encode()
+    hp.pool_begin(rows, 0, False)
+    with pytest.raises(hip.HipError):
+        hp.pool_admit_from(other, 0, 0)
+    with pytest.raises(hip.HipError):
+        hp.pool_admit_from(encs[0], batch + 3, 0)
+    other.close(); hp.close()
+    for h in encs:
+        h.close()
+    hm.close()
+
+
 def test_pool_no_speech_exit_max_new_tokens_languages_and_refusals():
     hip = _hip()
     name = "test-d128"

@@ -84,3 +84,47 @@ def test_pool_keeps_rows_busy_where_lockstep_batches_wait_for_the_longest():
     dp.run(len(lengths), e.encode)
     lockstep = sum(32 * max(lengths[g:g + 32]) for g in range(0, len(lengths), 32))
     assert dp.row_steps < 0.5 * lockstep
+
+
+class FakeEncoder:
+    def __init__(self):
+        self.rows = {}
+
+
+class FedEngine(FakeEngine):
+    def pool_admit_from(self, enc, src, dst, lang):
+        assert self.left[dst] is None and src in enc.rows
+        c = enc.rows.pop(src)
+        self.clip[dst], self.left[dst], self.lang[dst] = c, self.lengths[c] + self.prompt - 1, lang
+        self.log.append(("admit", c, dst))
+
+
+@pytest.mark.parametrize("rows,batch,n_enc,check", [(8, 5, 2, 4), (64, 32, 2, 16), (3, 7, 1, 1), (16, 4, 3, 2)])
+def test_one_pool_fed_by_encoder_contexts_admits_every_clip_once_in_order_and_reuses_a_context_only_when_it_is_drained(rows, batch, n_enc, check):
+    rng = np.random.default_rng(rows + batch)
+    N = 83
+    lengths = [int(x) for x in rng.choice([3, 10, 40, 120], size=N)]
+    e, encs = FedEngine(lengths), [FakeEncoder() for _ in range(n_enc)]
+    submissions = []
+
+    def encode(i, first, n):
+        assert not encs[i].rows                      # handed out again only when every clip of its last submission was admitted
+        encs[i].rows = {k: first + k for k in range(n)}
+        submissions.append((i, first, n))
+    fp = pool.FedDecodePool(e, encs, rows=rows, batch=batch, check_every=check)
+    res = fp.run(N, encode, langs=list(range(500, 500 + N)))
+    assert [r["clip"] for r in res] == list(range(N)) and [r["lang"] for r in res] == list(range(500, 500 + N))
+    assert [x[1] for x in e.log if x[0] == "admit"] == list(range(N))
+    assert [sbm[1] for sbm in submissions] == list(range(0, N, batch)) and [sbm[0] for sbm in submissions] == [k % n_enc for k in range(len(submissions))]
+    assert fp.encodes == len(submissions) and fp.row_steps >= sum(lengths) and e.max_concurrent <= rows
+
+
+def test_an_error_on_the_encoder_thread_reaches_the_caller():
+    e, encs = FedEngine([5] * 20), [FakeEncoder()]
+
+    def encode(i, first, n):
+        if first >= 8:
+            raise RuntimeError("encoder failed")
+        encs[i].rows = {k: first + k for k in range(n)}
+    with pytest.raises(RuntimeError):
+        pool.FedDecodePool(e, encs, rows=4, batch=4, check_every=2).run(20, encode)
