@@ -13,12 +13,19 @@
 //   * per-clip max - 8 clamp, /4 + 1.
 // This file is compiled with -ffp-contract=off: the reference does not fuse multiply-adds here.
 //
-// One wavefront per frame (4 frames per 256-thread workgroup), everything staged in LDS.
+// One wavefront per frame, everything staged in LDS.  16 frames per 1024-thread workgroup, and the workgroup asks for the WHOLE LDS
+// of its CU (it uses 133 KB of the 160): r03 found this kernel's FFT stages disturbed -- a few wrong spectra per clip, rarely --
+// whenever a workgroup of another stream whose MFMAs are fed from LDS reads (the logits GEMVs, the encoder GEMM / attention of
+// another context) ran on the same CU (DESIGN.md 5 "A neighbour on the CU", tests/test_gpu_load.py).  With four 256-thread
+// workgroups of 37 KB each a CU had room for such a neighbour; one workgroup holding all of the LDS has the same sixteen waves per
+// CU and no LDS-using neighbour, whoever it might be.
 #include "nh_kernels.h"
+#include <atomic>
 
 #define N_FFT 400
 #define HOP 160
-#define FRAMES_PER_WG 4
+#define FRAMES_PER_WG 16
+#define MEL_LDS_BYTES (160 * 1024)
 
 __device__ __forceinline__ unsigned f32_ordered(float f) {
     unsigned u = __float_as_uint(f);
@@ -34,16 +41,17 @@ struct MelArgs {
     int n_mel; int frames; float *mel32; unsigned *chunk_max;
 };
 
-__global__ __launch_bounds__(256) void logmel_kernel(MelArgs a) {
-    __shared__ float s_in[FRAMES_PER_WG][N_FFT];
-    __shared__ float s_a[FRAMES_PER_WG][2 * N_FFT];
-    __shared__ float s_b[FRAMES_PER_WG][2 * N_FFT];
-    __shared__ float s_dc[25 * 25], s_ds[25 * 25];
+__global__ __launch_bounds__(64 * FRAMES_PER_WG) void logmel_kernel(MelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float mel_lds[];
+    float (*s_in)[N_FFT] = reinterpret_cast<float (*)[N_FFT]>(mel_lds);
+    float (*s_a)[2 * N_FFT] = reinterpret_cast<float (*)[2 * N_FFT]>(mel_lds + FRAMES_PER_WG * N_FFT);
+    float (*s_b)[2 * N_FFT] = reinterpret_cast<float (*)[2 * N_FFT]>(mel_lds + FRAMES_PER_WG * 3 * N_FFT);
+    float *s_dc = mel_lds + FRAMES_PER_WG * 5 * N_FFT, *s_ds = s_dc + 25 * 25;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int b = blockIdx.y;
     const int frame = blockIdx.x * FRAMES_PER_WG + w;
     const bool live = frame < a.frames;
-    for (int i = tid; i < 625; i += 256) { s_dc[i] = a.t.dft_cos[i]; s_ds[i] = a.t.dft_sin[i]; }
+    for (int i = tid; i < 625; i += 64 * FRAMES_PER_WG) { s_dc[i] = a.t.dft_cos[i]; s_ds[i] = a.t.dft_sin[i]; }
     // windowed frame (samples at or beyond the clip's length are the zero padding of pcm_to_mel)
     {
         const int nv = a.n_samples[b];
@@ -161,7 +169,15 @@ void launch_logmel_grp(const float *pcm, const int32_t *n_samples, long stride, 
                        hipStream_t st) {
     MelArgs a{pcm, n_samples, stride, t, grp, n_mel, frames, mel32, chunk_max};
     dim3 grid((frames + FRAMES_PER_WG - 1) / FRAMES_PER_WG, B);
-    hipLaunchKernelGGL(logmel_kernel, grid, dim3(256), 0, st, a);
+    static std::atomic<bool> attr_set[NH_MAX_DEVICES];   // hipFuncSetAttribute acts on the current device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= NH_MAX_DEVICES || !attr_set[dev].load(std::memory_order_acquire)) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&logmel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, MEL_LDS_BYTES);
+        if (dev >= 0 && dev < NH_MAX_DEVICES) attr_set[dev].store(true, std::memory_order_release);
+    }
+    static_assert((FRAMES_PER_WG * 5 * N_FFT + 2 * 625) * 4 <= MEL_LDS_BYTES, "log-mel staging does not fit the LDS");
+    hipLaunchKernelGGL(logmel_kernel, grid, dim3(64 * FRAMES_PER_WG), MEL_LDS_BYTES, st, a);
 }
 
 void launch_mel_finish_ex(float *mel32, const unsigned *chunk_max, half_t *img, int B, int n_mel, int frames,

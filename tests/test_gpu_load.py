@@ -120,3 +120,34 @@ def test_three_decode_pools_in_flight_give_every_clip_the_result_it_has_alone():
     for h in pools_:
         h.close()
     hm.close()
+
+
+def test_encoders_of_several_contexts_overlapping_freely_with_a_decode_pool_small_model_many_repetitions():
+    """No host lock around the encoder submissions here: three encoder contexts feed one decoding context (pool.FedDecodePool) and
+    their log-mel, GEMM and attention kernels overlap each other and the decode steps as the GPU pleases.  Before the log-mel
+    kernel took its CU's whole LDS about one repetition in 130 came back with a submission's clips off in the low digits of
+    avg_logprob (tools/dbg/fed_case.py: 11 of 1500; 0 of 2000 since)."""
+    import test_gpu_pool as T
+    from norma_amd import hip
+    name, N, rows, batch, n_enc = "test-d128", 31, 5, 7, 3
+    cfg = config.preset(name)
+    tk = common.tokens_for(name)
+    hm = T._varlen_weights(cfg, tk, eot_steps=[2, 5, 9, 14, 22], text_steps=40, n_calib=8, max_batch=N)
+    clips = np.stack([synth.synth_pcm(k) for k in range(N)])
+    hm.logmel_array(clips); hm.encode()
+    want = hm.decode_greedy()
+    hp = hip.HipWhisper(cfg, device=0, max_batch=rows + 1, share_with=hm)
+    encs = [hip.HipWhisper(cfg, device=0, max_batch=batch, share_with=hm) for _ in range(n_enc)]
+    for h in [hp] + encs:
+        h.set_tokens(tk, tk.en, tk.transcribe)
+
+    def encode(i, first, n):
+        encs[i].logmel_array(np.ascontiguousarray(clips[first:first + n])); encs[i].encode()
+    bad = []
+    for rep in range(400):
+        got = pool.FedDecodePool(hp, encs, rows=rows, batch=batch, check_every=3).run(N, encode)
+        bad += [(rep, i) for i, (g, w) in enumerate(zip(got, want)) if not T._same(g, w)]
+    assert not bad, (len(bad), bad[:10])
+    hp.close(); hm.close()
+    for h in encs:
+        h.close()

@@ -22,8 +22,11 @@ bad = []
 lock = threading.Lock()
 def run(i):
     for r in range(ROUNDS):
-        with lock:
-            hs[i].logmel_array(clips); hs[i].encode(); hs[i].synchronize()
+        if os.environ.get("STRESS_NO_LOCK"):      # encoders of different contexts overlap freely
+            hs[i].logmel_array(clips); hs[i].encode()
+        else:
+            with lock:
+                hs[i].logmel_array(clips); hs[i].encode(); hs[i].synchronize()
         got = hs[i].decode_greedy()
         for k, (g, w) in enumerate(zip(got, want)):
             if g["tokens"] != w["tokens"] or g["avg_logprob"] != w["avg_logprob"] or g["no_speech_prob"] != w["no_speech_prob"]:
