@@ -3,7 +3,8 @@
 config 5  Whisper large-v3 multilingual (32 + 32 layers, V2 vocabulary), batch 64, language detection + timestamp decoding:
           Model::detect_language (src/models/whisper/model.rs:194-210), the [sot, lang, task] prompt (:285-289,
           multilingual.rs:383-398) and the timestamp rules (:212-277) -- one clip against the oracle end to end, then the
-          b64 batch through size-independent properties (determinism, clip alone == clip in the batch, bit for bit).
+          b64 batch through size-independent properties (determinism, clip alone == clip in the batch, bit for bit),
+          and the decode pool (nh_pool_*) at that size against the lockstep batch.
 config 4  distil-large-v3 long-form: a 10-minute clip = 20 chunks, sharded 3,3,3,3,2,2,2,2 (norma_amd.shard.partition);
           every rank's slice is run on the one GPU of the box, packed/unpacked like the RCCL gather does, and the union
           must equal the single 20-chunk pass; bench.py's own 2-rank launcher is run on top (gloo, both ranks on cuda:0).
@@ -91,6 +92,17 @@ def test_config5_large_v3_full_size_language_detection_and_timestamps():
     assert r64[9]["tokens"] == got["tokens"] and r64[9]["avg_logprob"] == got["avg_logprob"]
     assert r64[9]["no_speech_prob"] == got["no_speech_prob"]
     assert len({r["avg_logprob"] for r in r64}) > 32                      # the clips do differ: the log-probs depend on the audio
+    # ---- the decode pool at full size (nh_pool_*: 32 decoder layers = 64 cross-K/V moves per admitted clip, a language token per
+    # clip in the prompt): 48 clips through 40 decode rows + 24 staging rows of the same context == the lockstep b64 results
+    from norma_amd import pool
+    arr = np.stack(clips[:48])
+
+    def encode(first, n, row0, must=True):
+        h64.logmel_array_rows(np.ascontiguousarray(arr[first:first + n]), row0); h64.encode_rows(row0, n)
+    dp = pool.DecodePool(h64, rows=40, staging=24, check_every=8, per_clip_language=True)
+    pooled = dp.run(48, encode, langs=[want] * 48)
+    for k, (a, b) in enumerate(zip(pooled, r64[:48])):
+        assert a["tokens"] == b["tokens"] and a["avg_logprob"] == b["avg_logprob"] and a["no_speech_prob"] == b["no_speech_prob"], k
     h1.close(); h64.close()
 
 
