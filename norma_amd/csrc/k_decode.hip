@@ -823,6 +823,88 @@ __global__ __launch_bounds__(256) void dec_attn_kernel(const half_t *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// NUMERICS PROTOTYPE (NH_OPT_ABSORBED_XATTN, off by default): cross-attention computed on the encoder output
+// xa itself instead of on K = xa Wk^T and V = xa Wv^T + bv -- with u_h = Wk_h^T q_h the scores are xa . u_h, and
+// sum_s p_h[s] V[s] = Wv_h (sum_s p_h[s] xa[s]) + bv_h -- so that a decoder layer would stream xa (3.84 MB per row, shared by all
+// layers) once instead of K and V (7.68 MB per row and layer).  These two kernels exist to answer ONE question on the GPU before
+// the real (MFMA, one-pass) kernel is written: do the decoder tolerance tests survive moving the fp16 roundings from K and V to u
+// and z?  They place the roundings where that kernel would (u, p and z in fp16; sums in f32) and are not fast: every (row, head)
+// workgroup re-reads the whole xa of its row.
+__global__ __launch_bounds__(256) void xabs_u_kernel(const half_t *__restrict__ q, const half_t *__restrict__ Wk, half_t *__restrict__ U, int d) {
+    __shared__ float qs[NH_DH];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (tid < NH_DH) qs[tid] = (float)q[(long)b * d + h * NH_DH + tid];
+    __syncthreads();
+    for (int c = tid; c < d; c += 256) {
+        float acc = 0.f;
+#pragma unroll 8
+        for (int j = 0; j < NH_DH; j++) acc += (float)Wk[(long)(h * NH_DH + j) * d + c] * qs[j];
+        U[((long)b * gridDim.x + h) * d + c] = (half_t)(0.125f * acc);   // candle scales q and k by dh^-1/4 each: exactly 1/8
+    }
+}
+
+__global__ __launch_bounds__(256) void xabs_attn_kernel(const half_t *__restrict__ U, const half_t *__restrict__ xa, const half_t *__restrict__ Wv,
+                                                        const float *__restrict__ bv, half_t *__restrict__ out, int d, int S,
+                                                        const int32_t *__restrict__ done) {
+    extern __shared__ float xsm[];          // u[d], then per wave: m, l, z[d]
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (done && done[b]) return;
+    float *us = xsm, *zs = xsm + d;        // zs: [4][d + 2]
+    for (int c = tid; c < d; c += 256) us[c] = (float)U[((long)b * gridDim.x + h) * d + c];
+    __syncthreads();
+    const int nper = d / 64;               // features per lane (d % 64 == 0)
+    float z[20];                           // d <= 1280
+    for (int i = 0; i < nper; i++) z[i] = 0.f;
+    float m = -INFINITY, l = 0.f;
+    const half_t *xr = xa + (long)b * S * d;
+    for (int s = w; s < S; s += 4) {
+        float xv[20], dot = 0.f;
+        for (int i = 0; i < nper; i++) { xv[i] = (float)xr[(long)s * d + 64 * i + lane]; dot += xv[i] * us[64 * i + lane]; }
+        for (int o = 32; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+        const float mn = fmaxf(m, dot);
+        const float al = __expf(m - mn);
+        const float pr = (float)(half_t)__expf(dot - mn);     // P goes to the matrix pipe as fp16 in the real kernel
+        l = l * al + pr;
+        for (int i = 0; i < nper; i++) z[i] = z[i] * al + pr * xv[i];
+        m = mn;
+    }
+    for (int i = 0; i < nper; i++) zs[w * (d + 2) + 64 * i + lane] = z[i];
+    if (lane == 0) { zs[w * (d + 2) + d] = m; zs[w * (d + 2) + d + 1] = l; }
+    __syncthreads();
+    // merge the four waves in one fixed order, normalise, round z to fp16 (the B operand of the value projection)
+    float mm = zs[d], ll = zs[d + 1];
+    float f[4]; f[0] = 1.f;
+    for (int ww = 1; ww < 4; ww++) {
+        const float m2 = zs[ww * (d + 2) + d], l2 = zs[ww * (d + 2) + d + 1];
+        const float mn = fmaxf(mm, m2);
+        const float a1 = (mm == -INFINITY) ? 0.f : __expf(mm - mn), a2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
+        for (int k = 0; k < ww; k++) f[k] *= a1;
+        f[ww] = a2; ll = ll * a1 + l2 * a2; mm = mn;
+    }
+    __syncthreads();
+    const float inv = 1.0f / ll;
+    for (int c = tid; c < d; c += 256) {
+        float v = ((zs[c] * f[0] + zs[(d + 2) + c] * f[1]) + zs[2 * (d + 2) + c] * f[2]) + zs[3 * (d + 2) + c] * f[3];
+        us[c] = (float)(half_t)(v * inv);
+    }
+    __syncthreads();
+    {   // o_h[j] = Wv[64 h + j][:] . z + bv: four threads per output
+        const int j = tid >> 2, part = tid & 3;
+        const half_t *wr = Wv + (long)(h * NH_DH + j) * d;
+        float acc = 0.f;
+        for (int c = part; c < d; c += 4) acc += (float)wr[c] * us[c];
+        acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2);
+        if (part == 0) out[(long)b * d + h * NH_DH + j] = (half_t)(acc + bv[h * NH_DH + j]);
+    }
+}
+
+void launch_xabs_attention(const half_t *q, const half_t *Wkv, const float *bkv, const half_t *xa, half_t *U, half_t *out, int B, int H, int d, int S,
+                           const int32_t *done, hipStream_t st) {
+    hipLaunchKernelGGL(xabs_u_kernel, dim3(H, B), dim3(256), 0, st, q, Wkv, U, d);
+    hipLaunchKernelGGL(xabs_attn_kernel, dim3(H, B), dim3(256), sizeof(float) * (d + 4 * (d + 2)), st, U, xa, Wkv + (long)d * d, bkv + d, out, d, S, done);
+}
+
 void launch_dec_attention(const half_t *q, const half_t *kc, const half_t *vc, half_t *out, int B, int Tn,
                           int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st, int kv_head_major,
                           const int32_t *done) {

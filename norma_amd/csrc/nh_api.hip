@@ -117,6 +117,8 @@ struct nh_ctx {
     int graph_key[6] = {-1, -1, -1, -1, -1, -1};
     int token_gen = 0;  // bumped by nh_set_tokens; part of the graph key
     bool opt_graphs = true, opt_fuse_ln = true;  // nh_set_option
+    bool opt_absorbed = false;   // NH_OPT_ABSORBED_XATTN (numerics prototype)
+    half_t *xabs_u = nullptr;    // [max_batch][H][d] scratch of that prototype
     int dec_layer_limit = 0;    // parity view (NH_OPT_DECODER_LAYER_LIMIT): run only the first n decoder blocks; 0 = all
     std::vector<int32_t> seq_lang;  // per-sequence language tokens (LanguageState::Detect), empty = tk.lang for all
     int32_t *d_lang_tokens = nullptr, *d_lang_out = nullptr;
@@ -922,7 +924,8 @@ static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr,
         launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos_ptr, ctx->sd, 1, done);  // head-major cache
         skinny(ctx, ctx->datt, d, L.o, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
         ln_skinny(ctx, L.ln2, L.cq, B, d, d, SK_F16, ctx->dq, nullptr, nullptr, d, 0, C, nullptr);
-        launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, nullptr, ctx->sd, 1, done);  // head-major cross K/V
+        if (ctx->opt_absorbed) launch_xabs_attention(ctx->dq, L.ckv.w, L.ckv.b, ctx->xa16, ctx->xabs_u, ctx->datt, B, H, d, ctx->S, done, ctx->sd);
+        else launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, nullptr, ctx->sd, 1, done);  // head-major cross K/V
         skinny(ctx, ctx->datt, d, L.co, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
         ln_skinny(ctx, L.ln3, L.fc1, B, 4 * d, d, SK_GELU_F16, ctx->dhid, nullptr, nullptr, 4 * d, 0, C, nullptr);
         skinny(ctx, ctx->dhid, 4 * d, L.fc2, B, d, 4 * d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
@@ -1084,6 +1087,7 @@ extern "C" int nh_pool_begin(nh_ctx *ctx, int rows, int max_new_tokens, int per_
     if (!ctx->have_tokens) return ctx->fail(NH_ERR_STATE, "nh_pool_begin: call nh_set_tokens first");
     hipSetDevice(ctx->dev);
     if (int rc = ensure_decoder_repack(ctx)) return rc;
+    if (ctx->opt_absorbed) return ctx->fail(NH_ERR_STATE, "nh_pool_begin: the NH_OPT_ABSORBED_XATTN prototype covers lockstep decodes only");
     ctx->pool_rows = rows; ctx->pool_max_new = max_new_tokens;
     ctx->pool_prompt = (per_clip_language || ctx->tk.lang >= 0) ? 3 : 2;
     ctx->pool_per_clip_language = per_clip_language != 0;
@@ -1395,6 +1399,14 @@ extern "C" int nh_set_option(nh_ctx *ctx, int option, int value) {
     else if (option == NH_OPT_DECODER_LAYER_LIMIT) {
         if (value < 0 || value > ctx->c.decoder_layers) return ctx->fail(NH_ERR_INVALID, "nh_set_option: layer limit outside [0, decoder_layers]");
         ctx->dec_layer_limit = value; drop_graphs(ctx);
+    }
+    else if (option == NH_OPT_ABSORBED_XATTN) {
+        if (value && !ctx->xabs_u) {
+            hipSetDevice(ctx->dev);
+            ctx->xabs_u = dalloc<half_t>(ctx, (size_t)ctx->B * ctx->c.decoder_attention_heads * ctx->c.d_model);
+            if (!ctx->xabs_u) return ctx->fail(NH_ERR_NOMEM, "nh_set_option: hipMalloc failed");
+        }
+        ctx->opt_absorbed = value != 0; drop_graphs(ctx);
     }
     else return ctx->fail(NH_ERR_INVALID, "nh_set_option: unknown option " + std::to_string(option));
     return NH_OK;

@@ -204,6 +204,11 @@ void launch_dec_attention(const half_t *q, const half_t *kc, const half_t *vc, h
                           int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st, int kv_head_major = 0,
                           const int32_t *done = nullptr);
 
+// numerics prototype of cross-attention on the encoder output itself (NH_OPT_ABSORBED_XATTN; k_decode.hip): Wkv = the fused
+// [2 d][d] cross K/V projection (K rows first), bkv its bias, xa fp16 [B][S][d], U scratch fp16 [B][H][d]
+void launch_xabs_attention(const half_t *q, const half_t *Wkv, const float *bkv, const half_t *xa, half_t *U, half_t *out, int B, int H, int d, int S,
+                           const int32_t *done, hipStream_t st);
+
 // ---- logit processor: softmax + norma rules + argmax + bookkeeping -----------------------------------
 struct DecodeState {        // all device pointers
     int32_t *tokens;        // [B][ctx]

@@ -23,7 +23,7 @@ HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "norma_hip.h")
 N_SAMPLES = 480000
 N_FRAMES = 3000
 NH_DTYPE_F32, NH_DTYPE_F16 = 0, 1
-NH_OPT_DECODE_GRAPHS, NH_OPT_FUSE_DECODE_LAYERNORM, NH_OPT_DECODER_LAYER_LIMIT = 0, 1, 2
+NH_OPT_DECODE_GRAPHS, NH_OPT_FUSE_DECODE_LAYERNORM, NH_OPT_DECODER_LAYER_LIMIT, NH_OPT_ABSORBED_XATTN = 0, 1, 2, 3
 # NH_SAMPLE_* of include/norma_hip.h (the types of src/dtype.rs)
 SAMPLE_DTYPES = {np.dtype(np.float32): 0, np.dtype(np.float64): 1, np.dtype(np.int8): 2, np.dtype(np.int16): 3,
                  np.dtype(np.int32): 4, np.dtype(np.int64): 5, np.dtype(np.uint8): 6, np.dtype(np.uint16): 7,
@@ -159,8 +159,15 @@ class HipWhisper:
             raise HipError(rc, self.L.nh_last_error(None).decode())
         self._h = h
         self.batch = 0
+        self._experiment_switches()
 
     # -- lifetime ------------------------------------------------------------------------------
+    def _experiment_switches(self):
+        """NORMA_HIP_ABSORBED_XATTN=1: every context runs the NH_OPT_ABSORBED_XATTN numerics prototype (lets the whole parity suite
+        be run against it: DESIGN.md 8 item 1)."""
+        if os.environ.get("NORMA_HIP_ABSORBED_XATTN"):
+            self.set_option(NH_OPT_ABSORBED_XATTN, 1)
+
     def close(self):
         if getattr(self, "_h", None):
             self.L.nh_destroy(self._h)
