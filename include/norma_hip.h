@@ -257,8 +257,9 @@ int nh_set_profile_gemm(nh_ctx *ctx, int enable);
  * (model.rs:466-476) before the final LayerNorm, so a test can compare the hidden state against an oracle built with n decoder
  * layers and see how the fp16 error grows with depth; 0 (default) = all of them. */
 #define NH_OPT_DECODER_LAYER_LIMIT 2
-/* 1: cross-attention computed on the encoder output itself (u = Wk^T q, z = p^T xa, o = Wv z + bv) by slow prototype kernels that
- * place the fp16 roundings where a one-pass kernel would: a NUMERICS experiment for DESIGN.md 8 item 1, lockstep decodes only.
+/* Cross-attention computed on the encoder output itself (u = Wk^T q, z = p^T xa, o = Wv z + bv), lockstep
+ * decodes only.  1: slow prototype kernels that place the fp16 roundings where the one-pass kernel does (the numerics experiment);
+ * 2: the one-pass kernels (xa streamed once per decoder layer; d_model 512 / 768 / 1024 / 1280, other widths fall back to 1).
  * 0 (default): K and V as the reference computes them. */
 #define NH_OPT_ABSORBED_XATTN 3
 int nh_set_option(nh_ctx *ctx, int option, int value);

@@ -905,6 +905,331 @@ void launch_xabs_attention(const half_t *q, const half_t *Wkv, const float *bkv,
     hipLaunchKernelGGL(xabs_attn_kernel, dim3(H, B), dim3(256), sizeof(float) * (d + 4 * (d + 2)), st, U, xa, Wkv + (long)d * d, bkv + d, out, d, S, done);
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The one-pass form of the same arithmetic (NH_OPT_ABSORBED_XATTN = 2): xa is streamed ONCE per decoder layer.
+//   xabs_u_fast_kernel U[b][h][:] = 1/8 Wk_h^T q_bh (MFMA, A = the transposed weight), heads padded to 32
+//   xabs_main_kernel   one workgroup per (row, key range of 384): 32-key tiles of xa through LDS; per tile
+//                        S = xa_tile U^T           (MFMA 32x32x16, M = keys, N = heads, K = features split over the 8 waves,
+//                                                   partial sums met in LDS in wave order 0..7)
+//                        online softmax per head   (a head per lane, like the encoder attention kernel's query per lane)
+//                        z^T += xa_tile^T P        (M = features, N = heads, K = keys; the SAME LDS tile read column-wise with
+//                                                   ds_read_b64_tr_b16, P straight from the accumulator registers)
+//                      and writes (m, l, z) of its key range
+//   xabs_zmerge_kernel merges the four key ranges of a (row, head) in the order 0,1,2,3 and rounds z to fp16
+//   xabs_oproj_kernel  o_h = Wv_h z_h + bv_h
+// The key ranges are the same for every batch size (one merge tree: a clip alone == the clip in a batch, bit for bit).
+// LDS image of a tile: ten [32 rows][128 features] panels with 256-byte rows, chunk' = chunk ^ (((row & 3) << 2) | ((row >> 2) & 3))
+// (playbook T10 image (b): conflict-free for the row reads and the transposed reads); LDS row r holds key swap23(r) of the tile,
+// which makes accumulator registers 0-7 / 8-15 of a lane the tile's keys 8 hh + 0..7 / 16 + 8 hh + 0..7, i.e. P is the B operand.
+#define XA_KT 32                 // keys per tile
+#define XA_LEAVES 4              // key ranges per row
+__device__ __forceinline__ int xa_swap23(int x) { return (x & ~12) | ((x & 4) << 1) | ((x & 8) >> 1); }
+__device__ __forceinline__ int xa_off(int panel, int row, int ch) { return panel * 8192 + 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+// WkT[c][r] = Wk[r][c] (d x d): built once per model beside the tile-major repacks, so that u = Wk_h^T q reads 128 contiguous
+// bytes per feature
+__global__ __launch_bounds__(256) void transpose_sq_kernel(const half_t *__restrict__ in, half_t *__restrict__ out, int d) {
+    __shared__ half_t t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) t[r][tx] = in[(long)(by + r) * d + bx + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) out[(long)(bx + r) * d + by + tx] = t[tx][r];
+}
+void launch_transpose_sq(const half_t *in, half_t *out, int d, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_sq_kernel, dim3(d / 32, d / 32), dim3(256), 0, st, in, out, d);
+}
+
+// U[b][h][c] = 1/8 sum_j WkT[c][64 h + j] q[b][64 h + j] on the matrix pipe: per head a [d x 64] x [64 x rows] product.  One wave per
+// (head, 32 features, 32 rows): four k-steps of v_mfma_f32_32x32x16_f16, A = WkT rows (features), B = q rows (j ascending: one
+// summation order for every batch size; rows beyond R are clamped and not stored)
+__global__ __launch_bounds__(256) void xabs_u_fast_kernel(const half_t *__restrict__ q, const half_t *__restrict__ WkT, half_t *__restrict__ U, int d, int R) {
+    const int h = blockIdx.x, lane = threadIdx.x & 63, w = threadIdx.x >> 6, n = lane & 31, hh = lane >> 5;
+    const int c0 = (blockIdx.y * 4 + w) * 32, b0 = blockIdx.z * 32;
+    const int brow = min(b0 + n, R - 1);
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    half8 a[4], bq[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+        a[ks] = *reinterpret_cast<const half8 *>(WkT + (long)(c0 + n) * d + h * NH_DH + 16 * ks + 8 * hh);
+        bq[ks] = *reinterpret_cast<const half8 *>(q + (long)brow * d + h * NH_DH + 16 * ks + 8 * hh);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[ks], bq[ks], acc, 0, 0, 0);
+    if (b0 + n < R) {   // register j is feature c0 + 8 (j >> 2) + 4 hh + (j & 3), column n is the row
+        half_t *up = U + ((long)(b0 + n) * 32 + h) * d + c0 + 4 * hh;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; g4++) {
+            const half4 o = {(half_t)(0.125f * acc[4 * g4]), (half_t)(0.125f * acc[4 * g4 + 1]), (half_t)(0.125f * acc[4 * g4 + 2]), (half_t)(0.125f * acc[4 * g4 + 3])};
+            *reinterpret_cast<half4 *>(up + 8 * g4) = o;
+        }
+    }
+}
+
+template <int D>   // D = d_model, a multiple of 256
+__global__ __launch_bounds__(512) void xabs_main_kernel(const half_t *__restrict__ U, const half_t *__restrict__ xa, float *__restrict__ zpart,
+                                                        float *__restrict__ mlpart, int S, int H, const int32_t *__restrict__ done) {
+    constexpr int FW = D / 8;          // features per wave
+    constexpr int KS1 = FW / 16;       // k-steps of the score product per wave
+    constexpr int MB2 = FW / 32;       // 32-feature blocks of z^T per wave
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    char *tile = lds;                                            // XA_KT * D * 2 bytes
+    float *part = reinterpret_cast<float *>(lds + XA_KT * D * 2);   // [8][16][64]
+    float *red = part + 8 * 16 * 64;                             // [16][64]
+    const int leaf = blockIdx.x, b = blockIdx.y;
+    if (done && done[b]) return;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, hh = lane >> 5;
+    const int KL = (((S + XA_LEAVES - 1) / XA_LEAVES + XA_KT - 1) / XA_KT) * XA_KT;   // keys per range, a multiple of the tile
+    const int k0 = leaf * KL, k1 = min(S, k0 + KL);
+    const int ntile = k1 > k0 ? (k1 - k0 + XA_KT - 1) / XA_KT : 0;
+    const half_t *xr = xa + (long)b * S * D;
+    // B operand of the score product: U[head n][features of this wave], resident
+    half8 uf[KS1];
+#pragma unroll
+    for (int ks = 0; ks < KS1; ks++) uf[ks] = *reinterpret_cast<const half8 *>(U + ((long)b * 32 + n) * D + w * FW + 16 * ks + 8 * hh);
+    // staging: thread t moves chunk (t & 15) of every panel for key t >> 4 of the tile: one global base and one LDS base per tile,
+    // everything else immediate offsets (the generic piece mapping kept ten addresses live and spilled them -- and a scratch
+    // reload drains vmcnt, i.e. waits for the tile prefetch it sits in)
+    constexpr int NPAN = D / 128;
+    u32x4 stg[NPAN];
+    const int skk = tid >> 4, sch = tid & 15;
+    const int lds_st = xa_off(0, xa_swap23(skk), sch);
+    auto gload = [&](int t) {
+        int key = k0 + t * XA_KT + skk; if (key >= S) key = S - 1;
+        const half_t *gp = xr + (long)key * D + 8 * sch;
+#pragma unroll
+        for (int i = 0; i < NPAN; i++) stg[i] = *reinterpret_cast<const u32x4 *>(gp + 128 * i);
+    };
+    auto lstore = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPAN; i++) *reinterpret_cast<u32x4 *>(tile + lds_st + 8192 * i) = stg[i];
+    };
+    f32x16 z[MB2];
+#pragma unroll
+    for (int i = 0; i < MB2; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) z[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef XA_STAMPS
+    long long stamp[8]; int nst = 0;
+#define XA_STAMP() do { if (t == 5 && nst < 8) stamp[nst++] = __builtin_readcyclecounter(); } while (0)
+#else
+#define XA_STAMP() do { } while (0)
+#endif
+    if (ntile > 0) gload(0);
+    for (int t = 0; t < ntile; t++) {
+        XA_STAMP();
+        lstore();
+        __syncthreads();
+        XA_STAMP();
+        if (t + 1 < ntile) gload(t + 1);
+        // ---- S partial over this wave's features: A = tile rows (keys), row m = n
+        f32x16 sp = zero, sq = zero;     // two chains (even / odd k-steps), summed once
+#pragma unroll
+        for (int ks = 0; ks < KS1; ks++) {
+            const int f = w * FW + 16 * ks + 8 * hh;
+            const half8 a = *reinterpret_cast<const half8 *>(tile + xa_off(f >> 7, n, (f & 127) >> 3));
+            if (ks & 1) sq = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, uf[ks], sq, 0, 0, 0);
+            else sp = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, uf[ks], sp, 0, 0, 0);
+        }
+        XA_STAMP();
+#pragma unroll
+        for (int j = 0; j < 16; j++) part[(w * 16 + j) * 64 + lane] = sp[j] + sq[j];
+        __syncthreads();
+        XA_STAMP();
+        {   // wave w sums accumulator registers 2 w, 2 w + 1 of all eight partials, in wave order
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                const int j = 2 * w + jj;
+                float v = part[(0 * 16 + j) * 64 + lane];
+#pragma unroll
+                for (int ww = 1; ww < 8; ww++) v += part[(ww * 16 + j) * 64 + lane];
+                red[j * 64 + lane] = v;
+            }
+        }
+        __syncthreads();
+        XA_STAMP();
+        float sv[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) sv[j] = red[j * 64 + lane];
+        // ---- online softmax of head n over the tile's keys: register j is key (j & 7) + 8 hh + 16 (j >> 3) of the tile
+        const int kbase = k0 + t * XA_KT;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int key = kbase + (j & 7) + 8 * hh + 16 * (j >> 3);
+            if (key >= k1) sv[j] = -INFINITY;
+            mx = fmaxf(mx, sv[j]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m_run, mx);                 // finite: every tile holds at least one key < k1
+        const float al = __expf(m_run - mn);               // exp(-inf) = 0 on the first tile
+        float ps = 0.f;
+        half8 p0, p1;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const half_t a = (half_t)__expf(sv[j] - mn), c = (half_t)__expf(sv[8 + j] - mn);
+            p0[j] = a; p1[j] = c; ps += (float)a + (float)c;
+        }
+        ps += __shfl_xor(ps, 32);
+        l_run = l_run * al + ps;
+        m_run = mn;
+        // ---- z^T[features of this wave][heads] = al z^T + tile^T P: A by transposed reads, lane group G = lane >> 4
+        XA_STAMP();
+        const int G = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+        if (__builtin_amdgcn_ballot_w64(al != 1.0f) != 0) {   // the running maxima rarely move after the first tiles
+#pragma unroll
+            for (int fb = 0; fb < MB2; fb++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) z[fb][e] *= al;
+        }
+        // address of this lane's part of a transposed read: row = key 8 (G >> 1) + 4 half + q4 (+ 16 ts) of the tile, chunk pair c0.
+        // swap23 only moves bits 2 and 3 of the key: key = 16 ts + 8 g + 4 half + q4 -> row = 16 ts + 4 g + 8 half + q4
+        const int trow0 = 4 * (G >> 1) + q4;
+#pragma unroll
+        for (int fb = 0; fb < MB2; fb++) {
+            const int f0 = w * FW + 32 * fb + 16 * (G & 1);          // first feature of this group's 16 columns
+            const int panel = f0 >> 7, c0 = (f0 & 127) >> 3;          // chunk of 8 features; the group covers chunks c0, c0 + 1
+#pragma unroll
+            for (int ts = 0; ts < 2; ts++) {                          // k-step: keys 16 ts + 8 (G >> 1) + 0..7 of the tile
+                half8 a;
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    const int row = 16 * ts + 8 * half + trow0;
+                    typedef __fp16 fp16x4 __attribute__((ext_vector_type(4)));
+                    // (the tile is the start of the dynamic LDS; the builtin wants an LDS-qualified pointer)
+                    const fp16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4f16(
+                        (__attribute__((address_space(3))) fp16x4 *)(&lds[xa_off(panel, row, c0 + (p4 >> 1)) + 8 * (p4 & 1)]));
+                    a[4 * half + 0] = (half_t)v[0]; a[4 * half + 1] = (half_t)v[1]; a[4 * half + 2] = (half_t)v[2]; a[4 * half + 3] = (half_t)v[3];
+                }
+                z[fb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, ts == 0 ? p0 : p1, z[fb], 0, 0, 0);
+            }
+        }
+        XA_STAMP();
+        __syncthreads();   // every wave is done with the tile (and with red) before the next one is stored
+        XA_STAMP();
+    }
+#ifdef XA_STAMPS
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) {   // per wave: cycle counter at the eight points of tile 5
+        float *sp_ = mlpart + (long)gridDim.y * XA_LEAVES * 32 * 2 + w * 8;
+        for (int k = 0; k < 8; k++) sp_[k] = k < nst ? (float)(stamp[k] - stamp[0]) : -1.f;
+    }
+#endif
+    // ---- this key range's state: m, l per head; z[head][feature] f32.  Accumulator register j of block fb is feature
+    // 32 fb + 8 (j >> 2) + 4 hh + (j & 3) of this wave's range, column n is the head
+    if (n < H) {
+        float *zp = zpart + (((long)b * XA_LEAVES + leaf) * H + n) * D + w * FW;
+#pragma unroll
+        for (int fb = 0; fb < MB2; fb++)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const f32x4 v = {z[fb][4 * g4], z[fb][4 * g4 + 1], z[fb][4 * g4 + 2], z[fb][4 * g4 + 3]};
+                *reinterpret_cast<f32x4 *>(zp + 32 * fb + 8 * g4 + 4 * hh) = v;
+            }
+        if (w == 0 && hh == 0) {
+            float *ml = mlpart + (((long)b * XA_LEAVES + leaf) * 32 + n) * 2;
+            ml[0] = m_run; ml[1] = l_run;
+        }
+    }
+}
+
+// merge the key ranges of (row, head) in the order 0..3 and round z to fp16: one workgroup per (head, row), one round trip
+__global__ __launch_bounds__(256) void xabs_zmerge_kernel(const float *__restrict__ zpart, const float *__restrict__ mlpart, half_t *__restrict__ z16,
+                                                          int d, int H, const int32_t *__restrict__ done) {
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (done && done[b]) return;
+    float f[XA_LEAVES], mm = -INFINITY, ll = 0.f;
+#pragma unroll
+    for (int lf = 0; lf < XA_LEAVES; lf++) {
+        const float m2 = mlpart[(((long)b * XA_LEAVES + lf) * 32 + h) * 2], l2 = mlpart[(((long)b * XA_LEAVES + lf) * 32 + h) * 2 + 1];
+        const float mn = fmaxf(mm, m2);
+        const float a1 = (mm == -INFINITY) ? 0.f : __expf(mm - mn), a2 = (m2 == -INFINITY) ? 0.f : __expf(m2 - mn);
+#pragma unroll
+        for (int k = 0; k < lf; k++) f[k] *= a1;
+        f[lf] = a2; ll = ll * a1 + l2 * a2; mm = mn;
+    }
+    const float inv = 1.0f / ll;
+    for (int c = 4 * tid; c < d; c += 1024) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int lf = 0; lf < XA_LEAVES; lf++) v += *reinterpret_cast<const f32x4 *>(zpart + (((long)b * XA_LEAVES + lf) * H + h) * d + c) * f[lf];
+        const half4 o = {(half_t)(v[0] * inv), (half_t)(v[1] * inv), (half_t)(v[2] * inv), (half_t)(v[3] * inv)};
+        *reinterpret_cast<half4 *>(z16 + ((long)b * 32 + h) * d + c) = o;
+    }
+}
+
+// o_h = Wv_h z_h + bv_h on the matrix pipe: per head a [64 x d] x [d x rows] product.  One workgroup per (head, 32 rows); the eight
+// waves split d (k ascending inside a wave), their partial sums meet in LDS in wave order 0..7
+template <int D>
+__global__ __launch_bounds__(512) void xabs_oproj_kernel(const half_t *__restrict__ z16, const half_t *__restrict__ Wv, const float *__restrict__ bv,
+                                                         half_t *__restrict__ out, int R, const int32_t *__restrict__ done) {
+    constexpr int FW = D / 8, KS = FW / 16;
+    __shared__ float part[8][2][16][64];
+    const int h = blockIdx.x, b0 = blockIdx.y * 32, tid = threadIdx.x, lane = tid & 63, w = tid >> 6, n = lane & 31, hh = lane >> 5;
+    const int brow = min(b0 + n, R - 1);
+    half8 a0[KS], a1[KS], bz[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        const int c = w * FW + 16 * ks + 8 * hh;
+        a0[ks] = *reinterpret_cast<const half8 *>(Wv + (long)(h * NH_DH + n) * D + c);
+        a1[ks] = *reinterpret_cast<const half8 *>(Wv + (long)(h * NH_DH + 32 + n) * D + c);
+        bz[ks] = *reinterpret_cast<const half8 *>(z16 + ((long)brow * 32 + h) * D + c);
+    }
+    f32x16 o0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o1 = o0;
+#pragma unroll
+    for (int ks = 0; ks < KS; ks++) {
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0[ks], bz[ks], o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1[ks], bz[ks], o1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) { part[w][0][j][lane] = o0[j]; part[w][1][j][lane] = o1[j]; }
+    __syncthreads();
+    // 2 x 16 x 64 sums: thread t takes (block, register, lane) = (t >> 10 .. ) in four passes of 512
+#pragma unroll
+    for (int pss = 0; pss < 4; pss++) {
+        const int e = tid + 512 * pss, blk = e >> 10, jj = (e >> 6) & 15, ln = e & 63;
+        float v = part[0][blk][jj][ln];
+#pragma unroll
+        for (int ww = 1; ww < 8; ww++) v += part[ww][blk][jj][ln];
+        // register jj of lane ln: output 32 blk + 8 (jj >> 2) + 4 (ln >> 5) + (jj & 3), row b0 + (ln & 31)
+        const int jo = 32 * blk + 8 * (jj >> 2) + 4 * (ln >> 5) + (jj & 3), b = b0 + (ln & 31);
+        if (b < R && !(done && done[b])) out[(long)b * D + h * NH_DH + jo] = (half_t)(v + bv[h * NH_DH + jo]);
+    }
+}
+
+bool xabs_fast_supported(int d, int H) { return (d == 1280 || d == 1024 || d == 768 || d == 512) && H <= 32; }
+
+// scratch: U fp16 [B][32][d] (rows of heads >= H must be zero), zpart f32 [B][4][H][d], mlpart f32 [B][4][32][2]
+void launch_xabs_attention_fast(const half_t *q, const half_t *WkT, const half_t *Wkv, const float *bkv, const half_t *xa, half_t *U, float *zpart, float *mlpart,
+                                half_t *out, int B, int H, int d, int S, const int32_t *done, hipStream_t st) {
+    hipLaunchKernelGGL(xabs_u_fast_kernel, dim3(H, d / 128, (B + 31) / 32), dim3(256), 0, st, q, WkT, U, d, B);
+    const size_t lds = (size_t)XA_KT * d * 2 + (8 * 16 * 64 + 16 * 64) * sizeof(float);
+    static std::atomic<bool> attr_set[NH_MAX_DEVICES];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= NH_MAX_DEVICES || !attr_set[dev].load(std::memory_order_acquire)) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&xabs_main_kernel<1280>), hipFuncAttributeMaxDynamicSharedMemorySize, NH_LDS_EXCLUSIVE);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&xabs_main_kernel<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, NH_LDS_EXCLUSIVE);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&xabs_main_kernel<768>), hipFuncAttributeMaxDynamicSharedMemorySize, NH_LDS_EXCLUSIVE);
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&xabs_main_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, NH_LDS_EXCLUSIVE);
+        if (dev >= 0 && dev < NH_MAX_DEVICES) attr_set[dev].store(true, std::memory_order_release);
+    }
+    // MFMAs fed from LDS reads: the workgroup takes its CU's whole LDS (NH_LDS_EXCLUSIVE, see there); it uses `lds` bytes
+    const dim3 grid(XA_LEAVES, B);
+    if (d == 1280) hipLaunchKernelGGL((xabs_main_kernel<1280>), grid, dim3(512), lds_exclusive_bytes(lds), st, U, xa, zpart, mlpart, S, H, done);
+    else if (d == 1024) hipLaunchKernelGGL((xabs_main_kernel<1024>), grid, dim3(512), lds_exclusive_bytes(lds), st, U, xa, zpart, mlpart, S, H, done);
+    else if (d == 768) hipLaunchKernelGGL((xabs_main_kernel<768>), grid, dim3(512), lds_exclusive_bytes(lds), st, U, xa, zpart, mlpart, S, H, done);
+    else hipLaunchKernelGGL((xabs_main_kernel<512>), grid, dim3(512), lds_exclusive_bytes(lds), st, U, xa, zpart, mlpart, S, H, done);
+    // the merged z (fp16 [B][32][d]) takes U's place: U was consumed by the main kernel
+    hipLaunchKernelGGL(xabs_zmerge_kernel, dim3(H, B), dim3(256), 0, st, zpart, mlpart, U, d, H, done);
+    const dim3 og(H, (B + 31) / 32);
+    const half_t *Wv = Wkv + (long)d * d; const float *bvp = bkv + d;
+    if (d == 1280) hipLaunchKernelGGL((xabs_oproj_kernel<1280>), og, dim3(512), 0, st, U, Wv, bvp, out, B, done);
+    else if (d == 1024) hipLaunchKernelGGL((xabs_oproj_kernel<1024>), og, dim3(512), 0, st, U, Wv, bvp, out, B, done);
+    else if (d == 768) hipLaunchKernelGGL((xabs_oproj_kernel<768>), og, dim3(512), 0, st, U, Wv, bvp, out, B, done);
+    else hipLaunchKernelGGL((xabs_oproj_kernel<512>), og, dim3(512), 0, st, U, Wv, bvp, out, B, done);
+}
+
 void launch_dec_attention(const half_t *q, const half_t *kc, const half_t *vc, half_t *out, int B, int Tn,
                           int H, int d, int ctx, int Tk, const int32_t *pos_ptr, hipStream_t st, int kv_head_major,
                           const int32_t *done) {

@@ -117,8 +117,9 @@ struct nh_ctx {
     int graph_key[6] = {-1, -1, -1, -1, -1, -1};
     int token_gen = 0;  // bumped by nh_set_tokens; part of the graph key
     bool opt_graphs = true, opt_fuse_ln = true;  // nh_set_option
-    bool opt_absorbed = false;   // NH_OPT_ABSORBED_XATTN (numerics prototype)
-    half_t *xabs_u = nullptr;    // [max_batch][H][d] scratch of that prototype
+    int opt_absorbed = 0;        // NH_OPT_ABSORBED_XATTN: 1 = numerics prototype, 2 = one-pass kernels
+    half_t *xabs_u = nullptr;    // [max_batch][32][d] scratch (heads padded to 32, pad rows zero)
+    float *xabs_z = nullptr, *xabs_ml = nullptr;   // key-range partials of the one-pass form
     int dec_layer_limit = 0;    // parity view (NH_OPT_DECODER_LAYER_LIMIT): run only the first n decoder blocks; 0 = all
     std::vector<int32_t> seq_lang;  // per-sequence language tokens (LanguageState::Detect), empty = tk.lang for all
     int32_t *d_lang_tokens = nullptr, *d_lang_out = nullptr;
@@ -545,6 +546,10 @@ static int ensure_decoder_repack(nh_ctx *ctx) {
             for (auto &L : m.dec) {
                 ok = ok && one(L.qkv.wt, L.qkv.w, 3 * d, d) && one(L.o.wt, L.o.w, d, d) && one(L.cq.wt, L.cq.w, d, d) &&
                      one(L.co.wt, L.co.w, d, d) && one(L.fc1.wt, L.fc1.w, 4 * d, d) && one(L.fc2.wt, L.fc2.w, d, 4 * d);
+                // the cross K projection transposed ([feature][head dim]; NH_OPT_ABSORBED_XATTN reads Wk_h^T q from it)
+                if (ok && !L.ckv.wt) { L.ckv.wt = dalloc_into<half_t>(m.allocs, (size_t)d * d, false); moved = true; }
+                ok = ok && L.ckv.wt;
+                if (ok) launch_transpose_sq(L.ckv.w, L.ckv.wt, d, ctx->sd);
             }
             if (!ok) return ctx->fail(NH_ERR_NOMEM, "hipMalloc(tile-major decoder weights)");
             HIPCHK(hipStreamSynchronize(ctx->sd));
@@ -924,7 +929,8 @@ static void decoder_step(nh_ctx *ctx, int pos, const int32_t *pos_ptr = nullptr,
         launch_dec_attention(ctx->dq, L.sk, L.sv, ctx->datt, B, 1, H, d, C, pos + 1, pos_ptr, ctx->sd, 1, done);  // head-major cache
         skinny(ctx, ctx->datt, d, L.o, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
         ln_skinny(ctx, L.ln2, L.cq, B, d, d, SK_F16, ctx->dq, nullptr, nullptr, d, 0, C, nullptr);
-        if (ctx->opt_absorbed) launch_xabs_attention(ctx->dq, L.ckv.w, L.ckv.b, ctx->xa16, ctx->xabs_u, ctx->datt, B, H, d, ctx->S, done, ctx->sd);
+        if (ctx->opt_absorbed == 2) launch_xabs_attention_fast(ctx->dq, L.ckv.wt, L.ckv.w, L.ckv.b, ctx->xa16, ctx->xabs_u, ctx->xabs_z, ctx->xabs_ml, ctx->datt, B, H, d, ctx->S, done, ctx->sd);
+        else if (ctx->opt_absorbed) launch_xabs_attention(ctx->dq, L.ckv.w, L.ckv.b, ctx->xa16, ctx->xabs_u, ctx->datt, B, H, d, ctx->S, done, ctx->sd);
         else launch_dec_attention(ctx->dq, L.ck, L.cv, ctx->datt, B, 1, H, d, ctx->S, ctx->S, nullptr, ctx->sd, 1, done);  // head-major cross K/V
         skinny(ctx, ctx->datt, d, L.co, B, d, d, SK_RESID_F32, ctx->dx, nullptr, nullptr, d, 0, C);
         ln_skinny(ctx, L.ln3, L.fc1, B, 4 * d, d, SK_GELU_F16, ctx->dhid, nullptr, nullptr, 4 * d, 0, C, nullptr);
@@ -1401,12 +1407,19 @@ extern "C" int nh_set_option(nh_ctx *ctx, int option, int value) {
         ctx->dec_layer_limit = value; drop_graphs(ctx);
     }
     else if (option == NH_OPT_ABSORBED_XATTN) {
+        if (value < 0 || value > 2) return ctx->fail(NH_ERR_INVALID, "nh_set_option: NH_OPT_ABSORBED_XATTN takes 0, 1 or 2");
+        if (value == 2 && !xabs_fast_supported(ctx->c.d_model, ctx->c.decoder_attention_heads)) value = 1;   // widths the one-pass kernel is not built for
+        hipSetDevice(ctx->dev);
         if (value && !ctx->xabs_u) {
-            hipSetDevice(ctx->dev);
-            ctx->xabs_u = dalloc<half_t>(ctx, (size_t)ctx->B * ctx->c.decoder_attention_heads * ctx->c.d_model);
+            ctx->xabs_u = dalloc<half_t>(ctx, (size_t)ctx->B * 32 * ctx->c.d_model);
             if (!ctx->xabs_u) return ctx->fail(NH_ERR_NOMEM, "nh_set_option: hipMalloc failed");
         }
-        ctx->opt_absorbed = value != 0; drop_graphs(ctx);
+        if (value == 2 && !ctx->xabs_z) {
+            ctx->xabs_z = dalloc<float>(ctx, (size_t)ctx->B * 4 * ctx->c.decoder_attention_heads * ctx->c.d_model);
+            ctx->xabs_ml = dalloc<float>(ctx, (size_t)ctx->B * 4 * 32 * 2);
+            if (!ctx->xabs_z || !ctx->xabs_ml) return ctx->fail(NH_ERR_NOMEM, "nh_set_option: hipMalloc failed");
+        }
+        ctx->opt_absorbed = value; drop_graphs(ctx);
     }
     else return ctx->fail(NH_ERR_INVALID, "nh_set_option: unknown option " + std::to_string(option));
     return NH_OK;

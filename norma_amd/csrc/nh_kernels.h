@@ -209,6 +209,13 @@ void launch_dec_attention(const half_t *q, const half_t *kc, const half_t *vc, h
 void launch_xabs_attention(const half_t *q, const half_t *Wkv, const float *bkv, const half_t *xa, half_t *U, half_t *out, int B, int H, int d, int S,
                            const int32_t *done, hipStream_t st);
 
+// the one-pass form (xa streamed once per layer).  U fp16 [B][32][d] with the rows of heads >= H zero, zpart f32 [B][4][H][d],
+// mlpart f32 [B][4][32][2]
+bool xabs_fast_supported(int d, int H);
+void launch_transpose_sq(const half_t *in, half_t *out, int d, hipStream_t st);   // out[c][r] = in[r][c], d x d, d % 32 == 0
+void launch_xabs_attention_fast(const half_t *q, const half_t *WkT, const half_t *Wkv, const float *bkv, const half_t *xa, half_t *U, float *zpart, float *mlpart,
+                                half_t *out, int B, int H, int d, int S, const int32_t *done, hipStream_t st);
+
 // ---- logit processor: softmax + norma rules + argmax + bookkeeping -----------------------------------
 struct DecodeState {        // all device pointers
     int32_t *tokens;        // [B][ctx]

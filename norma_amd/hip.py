@@ -166,7 +166,7 @@ class HipWhisper:
         """NORMA_HIP_ABSORBED_XATTN=1: every context runs the NH_OPT_ABSORBED_XATTN numerics prototype (lets the whole parity suite
         be run against it: DESIGN.md 8 item 1)."""
         if os.environ.get("NORMA_HIP_ABSORBED_XATTN"):
-            self.set_option(NH_OPT_ABSORBED_XATTN, 1)
+            self.set_option(NH_OPT_ABSORBED_XATTN, int(os.environ["NORMA_HIP_ABSORBED_XATTN"]))
 
     def close(self):
         if getattr(self, "_h", None):

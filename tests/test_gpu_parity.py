@@ -438,14 +438,41 @@ def test_distil_large_v3_full_depth_one_clip_matches_the_oracle():
     # bars against the oracle.  (The whole parity suite passes with it switched on: profiles/r03_pytest_absorbed_xattn.log;
     # large-v3 at 32 decoder layers: hidden 1.88e-3 against 1.78e-3, logits 1.75e-3 sigma against 1.85e-3.)
     hip = _hip()
-    hm.set_option(hip.NH_OPT_ABSORBED_XATTN, 1)
-    hm.logmel([clip]); hm.encode()
-    alt = hm.decode_greedy()[0]
-    assert alt["tokens"] == ref["tokens"]
-    assert abs(alt["avg_logprob"] - ref["avg_logprob"]) <= 5e-3
-    assert abs(alt["no_speech_prob"] - ref["no_speech_prob"]) <= 0.02 * ref["no_speech_prob"] + 1e-9
-    assert alt["avg_logprob"] != got["avg_logprob"]          # it really is another arithmetic
+    for form in (1, 2):      # 1: the slow prototype, 2: the one-pass kernels (xa streamed once per layer, MFMA, transposed LDS reads)
+        hm.set_option(hip.NH_OPT_ABSORBED_XATTN, form)
+        hm.logmel([clip]); hm.encode()
+        alt = hm.decode_greedy()[0]
+        assert alt["tokens"] == ref["tokens"], form
+        assert abs(alt["avg_logprob"] - ref["avg_logprob"]) <= 5e-3, form
+        assert abs(alt["no_speech_prob"] - ref["no_speech_prob"]) <= 0.02 * ref["no_speech_prob"] + 1e-9, form
+        assert alt["avg_logprob"] != got["avg_logprob"]      # it really is another arithmetic
     hm.close(); om.close()
+
+
+def test_absorbed_cross_attention_one_pass_kernels_are_batch_invariant_bit_for_bit():
+    """NH_OPT_ABSORBED_XATTN = 2 keeps the invariant the lockstep / joint / pool machinery rests on: a clip alone == the clip in a
+    batch (the key ranges and every summation order are fixed, whatever the number of rows): 1 row against 37 (base.en, d = 512,
+    8 heads) and against 5 (distil-large-v3, d = 1280, 20 heads)."""
+    hip = _hip()
+    for name, nb in (("base.en", 37), ("distil-large-v3", 5)):
+        cfg = config.preset(name)
+        tk = common.tokens_for(name)
+        script = common.transcript_script(tk, n_segments=2, words_per_segment=5, seed=3)
+        over = common.scripted_overrides(cfg, tk, script)
+        hm = common.build_hip(cfg, tk, overrides=over, max_batch=nb)
+        h1 = hip.HipWhisper(cfg, device=0, max_batch=1, share_with=hm)
+        h1.set_tokens(tk, tk.en, tk.transcribe)
+        for h in (hm, h1):
+            h.set_option(hip.NH_OPT_ABSORBED_XATTN, 2)
+        clips = np.stack([synth.synth_pcm(k) for k in range(nb)])
+        hm.logmel_array(clips); hm.encode()
+        batch = hm.decode_greedy()
+        for k in (0, nb // 2, nb - 1):
+            h1.logmel_array(np.ascontiguousarray(clips[k:k + 1])); h1.encode()
+            one = h1.decode_greedy()[0]
+            assert one["tokens"] == batch[k]["tokens"] == [tk.sot, tk.en, tk.transcribe] + script
+            assert one["avg_logprob"] == batch[k]["avg_logprob"] and one["no_speech_prob"] == batch[k]["no_speech_prob"]
+        hm.close(); h1.close()
 
 
 def test_encoder_batches_decoded_together_give_what_they_give_alone():
