@@ -89,6 +89,8 @@ def parse_args(argv=None):
                     help="workload varlen: `value` is the length-bucketed / partition_balanced pass (default: arrival order)")
     ap.add_argument("--pool-contexts", type=int, default=2, help="workload varlen: decode pools in flight per GPU")
     ap.add_argument("--pool-check-every", type=int, default=16, help="workload varlen: decode steps between two looks at the rows' done flags")
+    ap.add_argument("--phased", action="store_true",
+                    help="A/B: the pipelines alternate between an encoder phase (all of them, one after the other) and a decode phase (all of them together)")
     ap.add_argument("--pool-encoders", type=int, default=2, help="workload varlen: encoder contexts feeding ONE decoding context (0: skip that pass)")
     ap.add_argument("--pool-fed", action="store_true", help="workload varlen: `value` is the pass with one decoding context fed by --pool-encoders encoder contexts")
     ap.add_argument("--pool", action="store_true",
@@ -340,10 +342,15 @@ def worker(args):
                 h.logmel_device_rows(pcm_dev.data_ptr(), n_samples, synth.N_SAMPLES, g * B)
                 h.encode_rows(g * B, B)
                 h.synchronize()
+        if phase_barrier is not None:     # --phased: every pipeline has encoded before any of them decodes, and the other way round
+            phase_barrier.wait()
         out = h.decode_greedy(max_new)
+        if phase_barrier is not None:
+            phase_barrier.wait()
         under_load.extend(out[k * B:(k + 1) * B] for k in range(groups))
         return out[:B]
 
+    phase_barrier = threading.Barrier(P) if args.phased and P > 1 else None
     under_load = []   # every batch result of the pipelined passes: compared with the one-batch-at-a-time result after the timed region
 
     def run_steps(n, max_new, P=P):
